@@ -1,0 +1,247 @@
+"""ctypes binding of include/fluidsolver.h.
+
+Every call goes through the C ABI exactly as a C/C++ host would; arrays cross the
+boundary as plain float pointers in the reference's dense x-fastest layout.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+FS_UX, FS_UY, FS_UZ, FS_RHO, FS_T, FS_P, FS_DIV = range(7)
+FIELD_NAMES = {FS_UX: "ux", FS_UY: "uy", FS_UZ: "uz", FS_RHO: "rho", FS_T: "T", FS_P: "p", FS_DIV: "div"}
+FS_SCHEME_RK4, FS_SCHEME_MACCORMACK = 0, 1
+FS_FLAG_NO_GRAPH = 1 << 0
+FS_FLAG_JACOBI_NAIVE = 1 << 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# every symbol include/fluidsolver.h declares
+EXPORTED_SYMBOLS = (
+    "fs_default_params", "fs_create", "fs_destroy", "fs_step", "fs_steps", "fs_sync", "fs_frame",
+    "fs_stage_source", "fs_stage_force", "fs_stage_advect", "fs_stage_divergence",
+    "fs_stage_jacobi", "fs_stage_project", "fs_stage_gradient", "fs_density_host",
+    "fs_velocity_host", "fs_field_host", "fs_field_size", "fs_field_upload", "fs_field_device",
+    "fs_residual", "fs_last_sweeps", "fs_last_error", "fs_version",
+)
+
+
+class FsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fluidsolver error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    """struct fs_params"""
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+        ("dt", C.c_float),
+        ("jacobi_iters", C.c_int),
+        ("scheme", C.c_int),
+        ("source_x", C.c_float), ("source_y", C.c_float), ("source_z", C.c_float),
+        ("source_radius", C.c_float),
+        ("source_rho", C.c_float), ("source_temperature", C.c_float),
+        ("temperature_env", C.c_float),
+        ("device", C.c_int),
+        ("flags", C.c_uint),
+        ("tolerance", C.c_float),
+        ("check_every", C.c_int),
+        ("max_sweeps", C.c_int),
+    ]
+
+
+class Layout(C.Structure):
+    """struct fs_layout"""
+    _fields_ = [
+        ("dx", C.c_int), ("dy", C.c_int), ("dz", C.c_int),
+        ("z0", C.c_int), ("nz_local", C.c_int), ("ghost", C.c_int),
+        ("pitch", C.c_size_t), ("plane", C.c_size_t),
+    ]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libfluidsolver.so")
+
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+
+
+def load_library():
+    """Load the HIP library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "fluidsolver_amd: %s is missing -- build it with `make` (hipcc --offload-arch=gfx950); "
+            "there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.fs_default_params.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
+    L.fs_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    for name in ("fs_destroy", "fs_step", "fs_sync", "fs_frame", "fs_stage_source", "fs_stage_force",
+                 "fs_stage_advect", "fs_stage_divergence", "fs_stage_project", "fs_stage_gradient",
+                 "fs_last_sweeps"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_int
+    L.fs_steps.argtypes = [vp, C.c_int]
+    L.fs_stage_jacobi.argtypes = [vp, C.c_int]
+    L.fs_density_host.argtypes = [vp]
+    L.fs_density_host.restype = _fp
+    L.fs_velocity_host.argtypes = [vp, C.c_int]
+    L.fs_velocity_host.restype = _fp
+    L.fs_field_host.argtypes = [vp, C.c_int]
+    L.fs_field_host.restype = _fp
+    L.fs_field_size.argtypes = [vp, C.c_int]
+    L.fs_field_size.restype = C.c_size_t
+    L.fs_field_upload.argtypes = [vp, C.c_int, _fp]
+    L.fs_field_device.argtypes = [vp, C.c_int, C.POINTER(_fp), C.POINTER(Layout)]
+    L.fs_residual.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.fs_last_error.restype = C.c_char_p
+    L.fs_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def field_shape(field, nx, ny, nz):
+    """numpy shape (z, y, x) of a dense field."""
+    if field == FS_UX:
+        return (nz, ny, nx + 1)
+    if field == FS_UY:
+        return (nz, ny + 1, nx)
+    if field == FS_UZ:
+        return (nz + 1, ny, nx)
+    return (nz, ny, nx)
+
+
+def default_params(nx, ny, nz, **kw):
+    """Reference defaults (Solver.h:58-81) for an nx x ny x nz grid, overridden by kw."""
+    L = load_library()
+    p = Params()
+    rc = L.fs_default_params(C.byref(p), nx, ny, nz)
+    if rc:
+        raise FsError(rc, L.fs_last_error().decode())
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError("fs_params has no member %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+class Solver:
+    """Mirror of the reference's ``class Solver`` (Solver.h:13-44).
+
+    ``Initialize`` / ``Update`` / ``GetDensityField`` keep the reference names and
+    meaning; the snake_case methods expose the rest of the C ABI.
+    """
+
+    def __init__(self, params=None, nx=64, ny=128, nz=64, **kw):
+        self._L = load_library()
+        self.params = params if params is not None else default_params(nx, ny, nz, **kw)
+        self._h = None
+
+    # -- reference interface ---------------------------------------------------
+    def Initialize(self):
+        if self._h is not None:
+            raise FsError(-6, "Initialize called twice")
+        h = C.c_void_p()
+        self._check(self._L.fs_create(C.byref(self.params), C.byref(h)))
+        self._h = h
+        return self
+
+    def Update(self):
+        self._check(self._L.fs_step(self._handle()))
+
+    def GetDensityField(self):
+        return self.field(FS_RHO)
+
+    def Advect(self):
+        self._check(self._L.fs_stage_advect(self._handle()))
+
+    def Project(self):
+        self._check(self._L.fs_stage_project(self._handle()))
+
+    # -- the rest of the C ABI -------------------------------------------------
+    def _handle(self):
+        if self._h is None:
+            raise FsError(-6, "solver not initialised")
+        return self._h
+
+    def _check(self, rc):
+        if rc:
+            raise FsError(rc, self._L.fs_last_error().decode())
+
+    def close(self):
+        if self._h is not None:
+            self._L.fs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        if self._h is None:
+            self.Initialize()
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def step(self, n=1):
+        self._check(self._L.fs_steps(self._handle(), n))
+
+    def sync(self):
+        self._check(self._L.fs_sync(self._handle()))
+
+    @property
+    def frame(self):
+        return self._L.fs_frame(self._handle())
+
+    def stage(self, name, *args):
+        self._check(getattr(self._L, "fs_stage_" + name)(self._handle(), *args))
+
+    def field(self, field):
+        """Dense host copy (z, y, x) of a field; synchronises."""
+        h = self._handle()
+        ptr = self._L.fs_field_host(h, field)
+        if not ptr:
+            raise FsError(-2, self._L.fs_last_error().decode())
+        p = self.params
+        shape = field_shape(field, p.nx, p.ny, p.nz)
+        return np.ctypeslib.as_array(ptr, shape=shape).copy()
+
+    def velocity(self, component):
+        h = self._handle()
+        ptr = self._L.fs_velocity_host(h, component)
+        if not ptr:
+            raise FsError(-2, self._L.fs_last_error().decode())
+        p = self.params
+        return np.ctypeslib.as_array(ptr, shape=field_shape(FS_UX + component, p.nx, p.ny, p.nz)).copy()
+
+    def upload(self, field, arr):
+        p = self.params
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        if a.shape != field_shape(field, p.nx, p.ny, p.nz):
+            raise ValueError("field %d wants shape %s, got %s" % (field, field_shape(field, p.nx, p.ny, p.nz), a.shape))
+        self._check(self._L.fs_field_upload(self._handle(), field, a.ctypes.data_as(_fp)))
+
+    def device_field(self, field):
+        ptr = _fp()
+        lay = Layout()
+        self._check(self._L.fs_field_device(self._handle(), field, C.byref(ptr), C.byref(lay)))
+        return C.cast(ptr, C.c_void_p).value, lay
+
+    def residual(self, which=0):
+        out = C.c_double()
+        self._check(self._L.fs_residual(self._handle(), which, C.byref(out)))
+        return out.value
+
+    @property
+    def last_sweeps(self):
+        return self._L.fs_last_sweeps(self._handle())

@@ -1,0 +1,65 @@
+// fs_kernels.h -- launch interface between the solver object and the gfx950 kernels.
+//
+// Device layout shared by every field of a solver (one slab per rank):
+//   element (x, y, z_global) lives at  base[x + y*pitch + (z_global - z0)*plane]
+// with pitch >= nx + 3 and plane = pitch * (ny + 3).  The floats of a row beyond the
+// field's own x extent, the rows beyond its y extent and the planes beyond its z
+// extent at a global wall are zero and are never written by any kernel.  Because rows
+// and planes are contiguous, x = -2,-1 of a row alias the zero tail of the previous row
+// and y = -2,-1 of a plane alias the zero tail rows of the previous plane, so a gather
+// whose indices are clamped to [-2, extent] reads 0 outside the field without a single
+// bounds test (that is the reference's zero-outside sample, Solver.cu:37-42).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct FsGrid {
+    int nx, ny, nz;   // global cell counts
+    int z0;           // global index of the first owned cell plane
+    int nzl;          // owned cell planes on this rank
+    int ghost;        // readable planes below z0 and above the last owned face plane
+    int pitch;        // floats per row
+    int plane;        // floats per z plane
+    int wall_lo;      // 1 if z0 is the global z = 0 wall
+    int wall_hi;      // 1 if z0 + nzl is the global z = nz wall
+};
+
+struct FsFields {
+    float *ux, *uy, *uz, *nux, *nuy, *nuz;
+    float *rho, *nrho, *T, *nT;
+    float *p, *np, *div;
+};
+
+struct FsSource {
+    float x, y, z, radius, rho0, T0;
+};
+
+namespace fsk {
+
+void fill_interior(hipStream_t st, const FsGrid& g, float* f, float value);
+void source(hipStream_t st, const FsGrid& g, const FsSource& src, float* rho, float* T);
+void force_uy(hipStream_t st, const FsGrid& g, float* uy, const float* T, float dt, float T_env);
+// dir 1,2,3: advect one velocity component from the old velocity (ux,uy,uz) into out.
+void advect_velocity(hipStream_t st, const FsGrid& g, int dir, const float* field, float* out,
+                     const float* ux, const float* uy, const float* uz, float dt, int scheme,
+                     int* halo_flag);
+// T and rho share one back-trace (same sample position, Solver.cu:381-383 with dir = 0).
+void advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
+                    float* nrho, const float* ux, const float* uy, const float* uz, float dt,
+                    int scheme, int* halo_flag);
+void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, const float* uy,
+                const float* uz);
+// one Jacobi sweep p -> np over the owned planes [zb, ze) (global indices)
+void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
+                  int zb, int ze);
+// `sweeps` Jacobi sweeps with temporal blocking where it pays; returns through *result_in_np
+// whether the final iterate ended in np (1) or p (0).  Single-slab (no halo exchange) only.
+void jacobi_multi(hipStream_t st, const FsGrid& g, float* p, float* np, const float* div,
+                  int sweeps, int naive, int* result_in_np);
+void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p);
+// sum over owned cells of (div + 6p - neighbours)^2 in binary64; partial must hold
+// residual_partials(g) doubles, out one double.
+int residual_partials(const FsGrid& g);
+void residual(hipStream_t st, const FsGrid& g, const float* p, const float* div, double* partial,
+              double* out);
+
+}  // namespace fsk

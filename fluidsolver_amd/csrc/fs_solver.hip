@@ -1,0 +1,493 @@
+// fs_solver.hip -- the solver object behind the C ABI of include/fluidsolver.h.
+//
+// Host-side orchestration of one simulation step on one z-slab: buffer ownership,
+// stage order (reference: CuSolver/Source/Solver.cu:1009-1114 UpdateCuda, 1145-1165
+// Advect, 1168-1189 Project on its Jacobi branch), ping-pong swaps (Solver.cu:181-186),
+// host getters (Solver.cu:1368-1372).
+#include "../../include/fluidsolver.h"
+#include "fs_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define FS_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(FS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct fs_solver {
+    fs_params prm{};
+    FsGrid g{};
+    FsFields f{};
+    int device = 0;
+    hipStream_t st = nullptr;
+    float* pool = nullptr;            // one allocation holding all 13 fields
+    size_t field_elems = 0;           // floats per field including slack and ghost planes
+    size_t origin = 0;                // offset of element (0,0,z0) inside a field
+    float* host[FS_NUM_FIELDS] = {};  // pinned dense host copies, allocated on first use
+    double* d_partial = nullptr;
+    double* d_res = nullptr;
+    int* d_flag = nullptr;
+    double* h_res = nullptr;          // pinned
+    int* h_flag = nullptr;            // pinned
+    int frame = 0;
+    int last_sweeps = 0;
+};
+
+namespace {
+
+void field_dims(const fs_solver* s, int field, int& dx, int& dy, int& dz)
+{
+    dx = s->g.nx + (field == FS_UX);
+    dy = s->g.ny + (field == FS_UY);
+    dz = s->g.nz + (field == FS_UZ);
+}
+
+float** field_slot(fs_solver* s, int field)
+{
+    switch (field) {
+    case FS_UX: return &s->f.ux;
+    case FS_UY: return &s->f.uy;
+    case FS_UZ: return &s->f.uz;
+    case FS_RHO: return &s->f.rho;
+    case FS_T: return &s->f.T;
+    case FS_P: return &s->f.p;
+    case FS_DIV: return &s->f.div;
+    default: return nullptr;
+    }
+}
+
+int check_flag(fs_solver* s)
+{
+    // only slabs with a non-wall z face can raise the halo flag
+    if (s->g.wall_lo && s->g.wall_hi) return FS_OK;
+    FS_HIP(hipMemcpyAsync(s->h_flag, s->d_flag, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    FS_HIP(hipStreamSynchronize(s->st));
+    if (*s->h_flag)
+        return fail(FS_ERR_HALO, "a back-trace left the %d ghost planes of the z-slab", s->g.ghost);
+    return FS_OK;
+}
+
+int run_jacobi(fs_solver* s, int sweeps)
+{
+    if (sweeps <= 0) return FS_OK;
+    int in_np = 0;
+    fsk::jacobi_multi(s->st, s->g, s->f.p, s->f.np, s->f.div, sweeps,
+                      (s->prm.flags & FS_FLAG_JACOBI_NAIVE) ? 1 : 0, &in_np);
+    if (in_np) std::swap(s->f.p, s->f.np);
+    // After an odd number of sweeps the previous iterate sits in np, as it does after the
+    // reference's per-sweep swap (Solver.cu:1183).  After an even number the blocked kernels
+    // may have used np as scratch; fs_residual(which=1) documents that.
+    s->last_sweeps += sweeps;
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+int residual_sync(fs_solver* s, const float* p, double* out)
+{
+    fsk::residual(s->st, s->g, p, s->f.div, s->d_partial, s->d_res);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipMemcpyAsync(s->h_res, s->d_res, sizeof(double), hipMemcpyDeviceToHost, s->st));
+    FS_HIP(hipStreamSynchronize(s->st));
+    *out = *s->h_res;
+    return FS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fs_last_error(void) { return g_err.c_str(); }
+
+const char* fs_version(void) { return "fluidsolver_amd 0.1 (gfx950)"; }
+
+int fs_default_params(fs_params* p, int nx, int ny, int nz)
+{
+    if (!p) return fail(FS_ERR_INVALID, "fs_default_params: null params");
+    std::memset(p, 0, sizeof(*p));
+    p->nx = nx;
+    p->ny = ny;
+    p->nz = nz;
+    p->dt = 0.2f;
+    p->jacobi_iters = 30;
+    p->scheme = FS_SCHEME_MACCORMACK;
+    p->source_x = nx / 2.f;
+    p->source_y = 10.f;
+    p->source_z = nz / 2.f;
+    p->source_radius = 7.0f;
+    p->source_rho = 0.1f;
+    p->source_temperature = 2.f;
+    p->temperature_env = 0.f;
+    p->device = -1;
+    p->flags = 0;
+    p->tolerance = 0.f;
+    p->check_every = 8;
+    p->max_sweeps = 10000;
+    return FS_OK;
+}
+
+int fs_destroy(fs_solver* s)
+{
+    if (!s) return FS_OK;
+    (void)hipSetDevice(s->device);
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    for (float*& h : s->host)
+        if (h) (void)hipHostFree(h);
+    if (s->h_res) (void)hipHostFree(s->h_res);
+    if (s->h_flag) (void)hipHostFree(s->h_flag);
+    if (s->d_partial) (void)hipFree(s->d_partial);
+    if (s->d_res) (void)hipFree(s->d_res);
+    if (s->d_flag) (void)hipFree(s->d_flag);
+    if (s->pool) (void)hipFree(s->pool);
+    if (s->st) (void)hipStreamDestroy(s->st);
+    delete s;
+    return FS_OK;
+}
+
+int fs_create(const fs_params* p, fs_solver** out)
+{
+    if (!p || !out) return fail(FS_ERR_INVALID, "fs_create: null argument");
+    *out = nullptr;
+    if (p->nx < 1 || p->ny < 1 || p->nz < 1 || p->nx > 4096 || p->ny > 4096 || p->nz > 4096)
+        return fail(FS_ERR_INVALID, "fs_create: grid %dx%dx%d outside 1..4096", p->nx, p->ny, p->nz);
+    if (p->jacobi_iters < 0) return fail(FS_ERR_INVALID, "fs_create: jacobi_iters < 0");
+    if (p->scheme != FS_SCHEME_RK4 && p->scheme != FS_SCHEME_MACCORMACK)
+        return fail(FS_ERR_INVALID, "fs_create: unknown scheme %d", p->scheme);
+    if (p->tolerance > 0.f && (p->check_every < 1 || p->max_sweeps < 1))
+        return fail(FS_ERR_INVALID, "fs_create: convergence mode needs check_every, max_sweeps >= 1");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FS_ERR_NO_DEVICE, "fs_create: no HIP device visible");
+    int dev = p->device;
+    if (dev < 0) FS_HIP(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(FS_ERR_NO_DEVICE, "fs_create: device %d of %d", dev, ndev);
+    FS_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    FS_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FS_ERR_NO_DEVICE, "fs_create: device %d is %s; this library holds gfx950 code only",
+                    dev, prop.gcnArchName);
+
+    fs_solver* s = new (std::nothrow) fs_solver;
+    if (!s) return fail(FS_ERR_INVALID, "fs_create: out of host memory");
+    s->prm = *p;
+    s->device = dev;
+    FsGrid& g = s->g;
+    g.nx = p->nx;
+    g.ny = p->ny;
+    g.nz = p->nz;
+    g.z0 = 0;
+    g.nzl = p->nz;
+    g.ghost = 2;
+    g.wall_lo = g.wall_hi = 1;
+    g.pitch = round_up(p->nx + 3, 16);
+    long long plane = (long long)g.pitch * (p->ny + 3);
+    long long planes = (long long)g.nzl + 1 + 2 * g.ghost;
+    if (plane * (p->nz + 4) >= (1LL << 31)) {
+        delete s;
+        return fail(FS_ERR_INVALID, "fs_create: %dx%dx%d needs more than 2^31 elements per field",
+                    p->nx, p->ny, p->nz);
+    }
+    g.plane = (int)plane;
+    // slack so that (x,y,z) = (-2,-2,z0-ghost) is addressable, kept 256-byte aligned
+    size_t slack = (size_t)round_up(2 * g.pitch + 2, 64);
+    s->origin = slack + (size_t)g.ghost * plane;
+    s->field_elems = (slack + (size_t)(planes * plane) + 63) / 64 * 64;
+
+    const int nfields = 13;
+    int rc = FS_OK;
+    do {
+        if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(FS_ERR_HIP, "fs_create: hipStreamCreate failed");
+            break;
+        }
+        size_t bytes = s->field_elems * nfields * sizeof(float);
+        hipError_t e = hipMalloc((void**)&s->pool, bytes);
+        if (e != hipSuccess) {
+            rc = fail(FS_ERR_HIP, "fs_create: hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+            break;
+        }
+        // Solver.cu:917-929: every field starts at zero (this also zeroes all padding)
+        if (hipMemsetAsync(s->pool, 0, bytes, s->st) != hipSuccess) {
+            rc = fail(FS_ERR_HIP, "fs_create: hipMemset failed");
+            break;
+        }
+        float** slots[nfields] = {&s->f.ux, &s->f.uy, &s->f.uz, &s->f.nux, &s->f.nuy, &s->f.nuz,
+                                  &s->f.rho, &s->f.nrho, &s->f.T, &s->f.nT, &s->f.p, &s->f.np,
+                                  &s->f.div};
+        for (int q = 0; q < nfields; ++q) *slots[q] = s->pool + (size_t)q * s->field_elems + s->origin;
+        int np = fsk::residual_partials(g);
+        if (hipMalloc((void**)&s->d_partial, sizeof(double) * np) != hipSuccess ||
+            hipMalloc((void**)&s->d_res, sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&s->d_flag, sizeof(int)) != hipSuccess ||
+            hipHostMalloc((void**)&s->h_res, sizeof(double)) != hipSuccess ||
+            hipHostMalloc((void**)&s->h_flag, sizeof(int)) != hipSuccess) {
+            rc = fail(FS_ERR_HIP, "fs_create: auxiliary allocation failed");
+            break;
+        }
+        (void)hipMemsetAsync(s->d_flag, 0, sizeof(int), s->st);
+        // Solver.cu:993-995: T = temperature_env
+        if (p->temperature_env != 0.f) fsk::fill_interior(s->st, g, s->f.T, p->temperature_env);
+        if (hipStreamSynchronize(s->st) != hipSuccess || hipGetLastError() != hipSuccess) {
+            rc = fail(FS_ERR_HIP, "fs_create: initialisation kernels failed");
+            break;
+        }
+    } while (0);
+    if (rc != FS_OK) {
+        std::string keep = g_err;
+        fs_destroy(s);
+        g_err = keep;
+        return rc;
+    }
+    *out = s;
+    return FS_OK;
+}
+
+int fs_stage_source(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    FS_HIP(hipSetDevice(s->device));
+    FsSource src{s->prm.source_x, s->prm.source_y, s->prm.source_z, s->prm.source_radius,
+                 s->prm.source_rho, s->prm.source_temperature};
+    fsk::source(s->st, s->g, src, s->f.rho, s->f.T);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+int fs_stage_force(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    FS_HIP(hipSetDevice(s->device));
+    fsk::force_uy(s->st, s->g, s->f.uy, s->f.T, s->prm.dt, s->prm.temperature_env);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+int fs_stage_advect(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    FS_HIP(hipSetDevice(s->device));
+    FsFields& f = s->f;
+    const float dt = s->prm.dt;
+    const int sc = s->prm.scheme;
+    // Solver.cu:1153-1158: all three components from the OLD velocity, then swap
+    fsk::advect_velocity(s->st, s->g, 1, f.ux, f.nux, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    fsk::advect_velocity(s->st, s->g, 2, f.uy, f.nuy, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    fsk::advect_velocity(s->st, s->g, 3, f.uz, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    std::swap(f.ux, f.nux);
+    std::swap(f.uy, f.nuy);
+    std::swap(f.uz, f.nuz);
+    // Solver.cu:1160-1164: T then rho with the NEW (advected, unprojected) velocity
+    fsk::advect_scalars(s->st, s->g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    std::swap(f.T, f.nT);
+    std::swap(f.rho, f.nrho);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+int fs_stage_divergence(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    FS_HIP(hipSetDevice(s->device));
+    fsk::divergence(s->st, s->g, s->f.div, s->f.ux, s->f.uy, s->f.uz);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+int fs_stage_jacobi(fs_solver* s, int sweeps)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    if (sweeps < 0) return fail(FS_ERR_INVALID, "fs_stage_jacobi: sweeps < 0");
+    FS_HIP(hipSetDevice(s->device));
+    s->last_sweeps = 0;
+    return run_jacobi(s, sweeps);
+}
+
+int fs_stage_project(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    int rc = fs_stage_divergence(s);
+    if (rc) return rc;
+    s->last_sweeps = 0;
+    if (s->prm.tolerance > 0.f) {
+        // convergence mode: groups of check_every sweeps until sum r^2 < tolerance
+        while (s->last_sweeps < s->prm.max_sweeps) {
+            int n = s->prm.check_every;
+            if (s->last_sweeps + n > s->prm.max_sweeps) n = s->prm.max_sweeps - s->last_sweeps;
+            rc = run_jacobi(s, n);
+            if (rc) return rc;
+            double r2 = 0.0;
+            rc = residual_sync(s, s->f.p, &r2);
+            if (rc) return rc;
+            if (r2 < (double)s->prm.tolerance) break;
+        }
+        return FS_OK;
+    }
+    return run_jacobi(s, s->prm.jacobi_iters);
+}
+
+int fs_stage_gradient(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    FS_HIP(hipSetDevice(s->device));
+    fsk::gradient(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->f.p);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+int fs_step(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    int rc;
+    if ((rc = fs_stage_source(s))) return rc;
+    if ((rc = fs_stage_force(s))) return rc;
+    if ((rc = fs_stage_advect(s))) return rc;
+    if ((rc = fs_stage_project(s))) return rc;
+    if ((rc = fs_stage_gradient(s))) return rc;
+    s->frame++;
+    return FS_OK;
+}
+
+int fs_steps(fs_solver* s, int n)
+{
+    for (int q = 0; q < n; ++q) {
+        int rc = fs_step(s);
+        if (rc) return rc;
+    }
+    return FS_OK;
+}
+
+int fs_sync(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    FS_HIP(hipSetDevice(s->device));
+    FS_HIP(hipStreamSynchronize(s->st));
+    return check_flag(s);
+}
+
+int fs_frame(const fs_solver* s) { return s ? s->frame : -1; }
+
+int fs_last_sweeps(const fs_solver* s) { return s ? s->last_sweeps : -1; }
+
+size_t fs_field_size(const fs_solver* s, int field)
+{
+    if (!s || field < 0 || field >= FS_NUM_FIELDS) return 0;
+    int dx, dy, dz;
+    field_dims(s, field, dx, dy, dz);
+    return (size_t)dx * dy * dz;
+}
+
+static int copy_field(fs_solver* s, int field, float* host, bool to_host)
+{
+    int dx, dy, dz;
+    field_dims(s, field, dx, dy, dz);
+    float* dev = *field_slot(s, field);
+    hipMemcpy3DParms prm;
+    std::memset(&prm, 0, sizeof(prm));
+    hipPitchedPtr d = make_hipPitchedPtr(dev, (size_t)s->g.pitch * sizeof(float), (size_t)dx,
+                                         (size_t)(s->g.plane / s->g.pitch));
+    hipPitchedPtr h = make_hipPitchedPtr(host, (size_t)dx * sizeof(float), (size_t)dx, (size_t)dy);
+    prm.srcPtr = to_host ? d : h;
+    prm.dstPtr = to_host ? h : d;
+    prm.extent = make_hipExtent((size_t)dx * sizeof(float), (size_t)dy, (size_t)dz);
+    prm.kind = to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+    FS_HIP(hipMemcpy3DAsync(&prm, s->st));
+    FS_HIP(hipStreamSynchronize(s->st));
+    return FS_OK;
+}
+
+const float* fs_field_host(fs_solver* s, int field)
+{
+    if (!s || field < 0 || field >= FS_NUM_FIELDS) {
+        fail(FS_ERR_INVALID, "fs_field_host: bad argument");
+        return nullptr;
+    }
+    if (hipSetDevice(s->device) != hipSuccess) {
+        fail(FS_ERR_HIP, "hipSetDevice failed");
+        return nullptr;
+    }
+    if (!s->host[field]) {
+        size_t bytes = fs_field_size(s, field) * sizeof(float);
+        if (hipHostMalloc((void**)&s->host[field], bytes) != hipSuccess) {
+            s->host[field] = nullptr;
+            fail(FS_ERR_HIP, "fs_field_host: pinned allocation of %zu bytes failed", bytes);
+            return nullptr;
+        }
+    }
+    if (copy_field(s, field, s->host[field], true) != FS_OK) return nullptr;
+    if (check_flag(s) != FS_OK) return nullptr;
+    return s->host[field];
+}
+
+const float* fs_density_host(fs_solver* s) { return fs_field_host(s, FS_RHO); }
+
+const float* fs_velocity_host(fs_solver* s, int component)
+{
+    if (component < 0 || component > 2) {
+        fail(FS_ERR_INVALID, "fs_velocity_host: component %d", component);
+        return nullptr;
+    }
+    return fs_field_host(s, FS_UX + component);
+}
+
+int fs_field_upload(fs_solver* s, int field, const float* src)
+{
+    if (!s || !src || field < 0 || field >= FS_NUM_FIELDS)
+        return fail(FS_ERR_INVALID, "fs_field_upload: bad argument");
+    FS_HIP(hipSetDevice(s->device));
+    return copy_field(s, field, const_cast<float*>(src), false);
+}
+
+int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layout)
+{
+    if (!s || !ptr || field < 0 || field >= FS_NUM_FIELDS)
+        return fail(FS_ERR_INVALID, "fs_field_device: bad argument");
+    *ptr = *field_slot(s, field);
+    if (layout) {
+        field_dims(s, field, layout->dx, layout->dy, layout->dz);
+        layout->z0 = s->g.z0;
+        layout->nz_local = s->g.nzl + ((field == FS_UZ) ? 1 : 0);
+        layout->ghost = s->g.ghost;
+        layout->pitch = (size_t)s->g.pitch;
+        layout->plane = (size_t)s->g.plane;
+    }
+    return FS_OK;
+}
+
+int fs_residual(fs_solver* s, int which, double* out)
+{
+    if (!s || !out || (which != 0 && which != 1))
+        return fail(FS_ERR_INVALID, "fs_residual: bad argument");
+    FS_HIP(hipSetDevice(s->device));
+    return residual_sync(s, which == 0 ? s->f.p : s->f.np, out);
+}
+
+}  // extern "C"

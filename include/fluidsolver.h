@@ -1,0 +1,148 @@
+/*
+ * fluidsolver.h -- C ABI of the MI355X (gfx950) smoke-solver step.
+ *
+ * This is the drop-in boundary under the reference's C++ `Solver` class
+ * (reference: CuSolver/Include/Solver.h:13-167).  Plain pointers and sizes only;
+ * every function returns 0 on success or a negative fs_status, and stores a
+ * message retrievable with fs_last_error() (thread-local).
+ *
+ * Threading contract (same as the reference: one host thread drives one solver,
+ * CuSolver/Source/Solver.cu uses the default stream only): calls on one
+ * fs_solver must not overlap.  fs_step() only enqueues GPU work; the *_host
+ * getters, fs_sync() and fs_residual() synchronise.
+ *
+ * All fields are fp32 on a staggered grid, h = 1 (Solver.cu:17-27, 377-390):
+ *   FS_UX (nx+1,ny,nz)  FS_UY (nx,ny+1,nz)  FS_UZ (nx,ny,nz+1)
+ *   FS_RHO, FS_T, FS_P, FS_DIV (nx,ny,nz)
+ * Host-side buffers use the reference's dense layout, flat index
+ * x + y*dx + z*dx*dy (Solver.cu:33).  Device buffers are padded; see fs_layout.
+ */
+#ifndef FLUIDSOLVER_H
+#define FLUIDSOLVER_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define FS_API
+#else
+#define FS_API __attribute__((visibility("default")))
+#endif
+
+typedef enum fs_status {
+    FS_OK = 0,
+    FS_ERR_INVALID = -1,     /* bad argument */
+    FS_ERR_HIP = -2,         /* a HIP runtime call failed */
+    FS_ERR_NO_DEVICE = -3,   /* no usable gfx950 device */
+    FS_ERR_HALO = -4,        /* a back-trace left the ghost planes of a z-slab */
+    FS_ERR_COMM = -5,        /* RCCL failure */
+    FS_ERR_STATE = -6        /* call not valid in this state */
+} fs_status;
+
+/* field selectors */
+enum { FS_UX = 0, FS_UY = 1, FS_UZ = 2, FS_RHO = 3, FS_T = 4, FS_P = 5, FS_DIV = 6, FS_NUM_FIELDS = 7 };
+
+/* back-trace scheme of the semi-Lagrangian advection (Solver.cu:11, 393-397) */
+enum { FS_SCHEME_RK4 = 0, FS_SCHEME_MACCORMACK = 1 };
+
+/* fs_params.flags */
+enum {
+    FS_FLAG_NO_GRAPH = 1 << 0,   /* launch kernels eagerly instead of replaying a hipGraph */
+    FS_FLAG_JACOBI_NAIVE = 1 << 1 /* one kernel launch per sweep, no temporal blocking */
+};
+
+/*
+ * Run-time form of what the reference fixes at compile time:
+ * grid size macros Nx,Ny,Nz (Solver.h:9-11) and the member initialisers
+ * Solver.h:58-81.  fs_default_params() fills the reference values.
+ */
+typedef struct fs_params {
+    int nx, ny, nz;              /* Solver.h:58-60; 1 <= n <= 4096 each */
+    float dt;                    /* Solver.h:71   0.2  */
+    int jacobi_iters;            /* Solver.h:68   max_iter = 30, sweeps per step */
+    int scheme;                  /* Solver.cu:11  FS_SCHEME_MACCORMACK */
+    float source_x;              /* Solver.h:78   Nx/2 */
+    float source_y;              /* Solver.h:79   10   */
+    float source_z;              /* Solver.h:80   Nz/2 */
+    float source_radius;         /* Solver.h:81   7    */
+    float source_rho;            /* Solver.h:62   0.1  */
+    float source_temperature;    /* Solver.h:64   2.0  */
+    float temperature_env;       /* Solver.h:65   0.0  */
+    int device;                  /* HIP device ordinal; -1 = current device */
+    unsigned flags;              /* FS_FLAG_* */
+    /* convergence mode (weak-scaling config): if tolerance > 0, each step sweeps
+       in groups of check_every until sum r^2 < tolerance or max_sweeps is hit.
+       jacobi_iters is ignored in that mode. */
+    float tolerance;
+    int check_every;
+    int max_sweeps;
+} fs_params;
+
+/* Device-side layout of one field (all fields of a solver share the strides). */
+typedef struct fs_layout {
+    int dx, dy, dz;              /* logical dims of the field (global) */
+    int z0;                      /* global z index of the first plane held locally */
+    int nz_local;                /* number of owned planes of this field on this rank */
+    int ghost;                   /* readable ghost planes on each z side */
+    size_t pitch;                /* floats between consecutive y rows     */
+    size_t plane;                /* floats between consecutive z planes   */
+} fs_layout;
+
+typedef struct fs_solver fs_solver;
+
+/* -- lifetime: replaces Solver::Solver/Initialize/~Solver (Solver.cu:1116-1143) -- */
+FS_API int fs_default_params(fs_params* p, int nx, int ny, int nz);
+/* Allocates and zeroes every device field, sets T = temperature_env
+   (Solver.cu:879-952, 993-995). */
+FS_API int fs_create(const fs_params* p, fs_solver** out);
+FS_API int fs_destroy(fs_solver* s);
+
+/* -- stepping: replaces Solver::Update -> UpdateCuda (Solver.cu:1009-1114, 1132-1137)
+      with VORT_CONFINE off and Project() on its Jacobi branch (Solver.cu:1178-1189) -- */
+FS_API int fs_step(fs_solver* s);
+FS_API int fs_steps(fs_solver* s, int n);
+FS_API int fs_sync(fs_solver* s);
+FS_API int fs_frame(const fs_solver* s);          /* Solver.h:76 current_frame */
+
+/* -- individual stages, in the order fs_step runs them.  The reference exposes
+      Advect() and Project() as public members (Solver.h:24,26); the others are its
+      kernel launches at Solver.cu:1028, 1031 and 1111-1113. -- */
+FS_API int fs_stage_source(fs_solver* s);         /* SourceKernel      Solver.cu:295-307 */
+FS_API int fs_stage_force(fs_solver* s);          /* ForceKernelUy     Solver.cu:346-368 */
+FS_API int fs_stage_advect(fs_solver* s);         /* Solver::Advect    Solver.cu:1145-1165 */
+FS_API int fs_stage_divergence(fs_solver* s);     /* DivergenceKernel  Solver.cu:406-423 */
+FS_API int fs_stage_jacobi(fs_solver* s, int sweeps); /* JacobiKernel + swap, Solver.cu:426-443, 1180-1184 */
+FS_API int fs_stage_project(fs_solver* s);        /* Solver::Project   Solver.cu:1168-1189 */
+FS_API int fs_stage_gradient(fs_solver* s);       /* ApplyGradientU*   Solver.cu:446-483 */
+
+/* -- buffer access: replaces Solver::GetDensityField (Solver.cu:1368-1372).
+      Returned host pointers are solver-owned (pinned), dense reference layout,
+      valid until the next getter call for the same field or fs_destroy. -- */
+FS_API const float* fs_density_host(fs_solver* s);
+FS_API const float* fs_velocity_host(fs_solver* s, int component /* 0,1,2 */);
+FS_API const float* fs_field_host(fs_solver* s, int field);
+FS_API size_t fs_field_size(const fs_solver* s, int field);      /* element count, dense */
+/* Upload a dense host array into a field (tests, restart from a dump). */
+FS_API int fs_field_upload(fs_solver* s, int field, const float* src);
+/* Zero-copy access for device-side consumers. *ptr addresses element (0,0,z0). */
+FS_API int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layout);
+
+/* -- residual: what Mul + Reduce are meant to yield at Solver.cu:1185-1187:
+      sum over the grid of r^2 with r = div + 6p - sum(neighbours) (Solver.cu:442),
+      accumulated in binary64.  which = 0: r of the current pressure;
+      which = 1: r of the input iterate of the last sweep (what the reference's r
+      array holds after its loop). -- */
+FS_API int fs_residual(fs_solver* s, int which, double* out);
+/* sweeps the last fs_step / fs_stage_project actually ran (convergence mode) */
+FS_API int fs_last_sweeps(const fs_solver* s);
+
+FS_API const char* fs_last_error(void);
+FS_API const char* fs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDSOLVER_H */

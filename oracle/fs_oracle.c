@@ -1,0 +1,488 @@
+/*
+ * fs_oracle.c -- CPU restatement of the CuSolver simulation step (Jacobi branch).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped library links, loads or calls
+ * this file; it is the checker that the HIP path is compared against (tests/,
+ * the smoke check and the cpu_baseline leg of bench.py).
+ *
+ * PARITY PINNING: the reference holds no golden vectors, known-answer tests or
+ * fixtures for this path and its CUDA source cannot be compiled or run here, so
+ * this restatement is "parity unpinned" by upstream data.  It is pinned only by
+ * following the reference source expression by expression (citations below, all
+ * relative to /root/reference) and by analytic known-answer tests in tests/.
+ *
+ * Arithmetic contract: every expression is evaluated in IEEE binary32 in the
+ * association order the reference source spells, with NO fused multiply-add
+ * (build with -ffp-contract=off -fno-fast-math).  nvcc's default -fmad=true would
+ * contract some a*b+c in the shipped reference binary in a pattern the source does
+ * not determine; the language-level (uncontracted) meaning is what is restated.
+ *
+ * Layout: every array is x-fastest, flat index x + y*dx + z*dx*dy with
+ * (dx,dy,dz) the dims of that array (CuSolver/Source/Solver.cu:33,41).
+ *   ux (nx+1,ny,nz)  uy (nx,ny+1,nz)  uz (nx,ny,nz+1)  others (nx,ny,nz)
+ *   (Solver.cu:881-893)
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "fs_oracle.h"
+
+typedef struct { int x, y, z; } i3;
+typedef struct { float x, y, z; } f3;
+
+static inline i3 mk_i3(int a, int b, int c) { i3 r; r.x = a; r.y = b; r.z = c; return r; }
+static inline f3 mk_f3(float a, float b, float c) { f3 r; r.x = a; r.y = b; r.z = c; return r; }
+
+/* Math.cuh:21-31 */
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* Math.cuh:33-39 -- clamp every index into [0, dim-1] */
+static inline i3 minmax3(i3 pos, i3 max_pos)
+{
+    pos.x = imax(0, imin(pos.x, max_pos.x - 1));
+    pos.y = imax(0, imin(pos.y, max_pos.y - 1));
+    pos.z = imax(0, imin(pos.z, max_pos.z - 1));
+    return pos;
+}
+
+static inline size_t flat(i3 pos, i3 max_pos)
+{
+    return (size_t)pos.x + (size_t)pos.y * (size_t)max_pos.x +
+           (size_t)pos.z * (size_t)max_pos.x * (size_t)max_pos.y;
+}
+
+/* Solver.cu:30-34 -- replicate-edge point sample */
+static inline float sample(const float* field, i3 pos, i3 max_pos)
+{
+    pos = minmax3(pos, max_pos);
+    return field[flat(pos, max_pos)];
+}
+
+/* Solver.cu:37-42 -- zero-outside point sample */
+static inline float cg_sample(const float* field, i3 pos, i3 max_pos)
+{
+    if (pos.x < 0 || pos.x >= max_pos.x || pos.y < 0 || pos.y >= max_pos.y ||
+        pos.z < 0 || pos.z >= max_pos.z)
+        return 0;
+    return field[flat(pos, max_pos)];
+}
+
+/* Math.cuh:57-60 */
+static inline float lerpf(float a, float b, float s)
+{
+    return a * (1 - s) + b * s;
+}
+
+/* Math.cuh:80-118 float3 operators, spelled out so the association is explicit */
+static inline f3 f3_scale(float a, f3 b) { b.x *= a; b.y *= a; b.z *= a; return b; } /* :80-86  */
+static inline f3 f3_sub(f3 a, f3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; } /* :96-102 */
+static inline f3 f3_add(f3 a, f3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; } /* :104-110*/
+static inline f3 f3_div(f3 a, float b) { a.x /= b; a.y /= b; a.z /= b; return a; }    /* :112-118*/
+
+/* Solver.cu:52-113 */
+static float trilerp(const float* field, f3 pos, float fpos_x, float fpos_y, float fpos_z,
+                     i3 max_pos, int b_minmax_sample)
+{
+    float x = pos.x - fpos_x;
+    float y = pos.y - fpos_y;
+    float z = pos.z - fpos_z;
+
+    int ix = (int)x;             /* truncation toward zero, :58-60 */
+    int iy = (int)y;
+    int iz = (int)z;
+
+    float fx = x - floorf(x);    /* :62-64 */
+    float fy = y - floorf(y);
+    float fz = z - floorf(z);
+
+    /* :66-82 -- the comparison is float-vs-double-literal, i.e. done in double */
+    if ((double)x < -1e-6) { ix -= 1; fx = x - (float)ix; }
+    if ((double)y < -1e-6) { iy -= 1; fy = y - (float)iy; }
+    if ((double)z < -1e-6) { iz -= 1; fz = z - (float)iz; }
+
+    float a, b, c, d, e, f, g, h;
+    if (b_minmax_sample) {       /* :86-96 */
+        a = sample(field, mk_i3(ix, iy, iz), max_pos);
+        b = sample(field, mk_i3(ix + 1, iy, iz), max_pos);
+        c = sample(field, mk_i3(ix, iy + 1, iz), max_pos);
+        d = sample(field, mk_i3(ix + 1, iy + 1, iz), max_pos);
+        e = sample(field, mk_i3(ix, iy, iz + 1), max_pos);
+        f = sample(field, mk_i3(ix + 1, iy, iz + 1), max_pos);
+        g = sample(field, mk_i3(ix, iy + 1, iz + 1), max_pos);
+        h = sample(field, mk_i3(ix + 1, iy + 1, iz + 1), max_pos);
+    } else {                     /* :97-107 */
+        a = cg_sample(field, mk_i3(ix, iy, iz), max_pos);
+        b = cg_sample(field, mk_i3(ix + 1, iy, iz), max_pos);
+        c = cg_sample(field, mk_i3(ix, iy + 1, iz), max_pos);
+        d = cg_sample(field, mk_i3(ix + 1, iy + 1, iz), max_pos);
+        e = cg_sample(field, mk_i3(ix, iy, iz + 1), max_pos);
+        f = cg_sample(field, mk_i3(ix + 1, iy, iz + 1), max_pos);
+        g = cg_sample(field, mk_i3(ix, iy + 1, iz + 1), max_pos);
+        h = cg_sample(field, mk_i3(ix + 1, iy + 1, iz + 1), max_pos);
+    }
+
+    float lerp1 = lerpf(lerpf(a, b, fx), lerpf(c, d, fx), fy);   /* :109 */
+    float lerp2 = lerpf(lerpf(e, f, fx), lerpf(g, h, fx), fy);   /* :110 */
+    return lerpf(lerp1, lerp2, fz);                              /* :112 */
+}
+
+/* velocity at a point: the three staggered gathers every RK stage does (:142-144) */
+static inline f3 velocity_at(const float* ux, const float* uy, const float* uz, f3 pos,
+                             int nx, int ny, int nz)
+{
+    f3 u;
+    u.x = trilerp(ux, pos, 0.f, 0.5f, 0.5f, mk_i3(nx + 1, ny, nz), 0);
+    u.y = trilerp(uy, pos, 0.5f, 0.f, 0.5f, mk_i3(nx, ny + 1, nz), 0);
+    u.z = trilerp(uz, pos, 0.5f, 0.5f, 0.f, mk_i3(nx, ny, nz + 1), 0);
+    return u;
+}
+
+/* Solver.cu:139-161 */
+static f3 RK4(const float* ux, const float* uy, const float* uz, f3 pos, float dt,
+              int nx, int ny, int nz)
+{
+    f3 u1 = velocity_at(ux, uy, uz, pos, nx, ny, nz);
+    f3 p1 = f3_sub(pos, f3_scale(0.5f * dt, u1));                 /* :145 */
+    f3 u2 = velocity_at(ux, uy, uz, p1, nx, ny, nz);
+    f3 p2 = f3_sub(pos, f3_scale(0.5f * dt, u2));                 /* :150 */
+    f3 u3 = velocity_at(ux, uy, uz, p2, nx, ny, nz);
+    f3 p3 = f3_sub(pos, f3_scale(dt, u3));                        /* :155 */
+    f3 u4 = velocity_at(ux, uy, uz, p3, nx, ny, nz);
+    /* :160  pos - dt * (u1 + 2.0*u2 + 2.0*u3 + u4) / 6.0 ; the double literals
+       convert to float through the operator signatures (Math.cuh:80,112). */
+    f3 sum = f3_add(f3_add(f3_add(u1, f3_scale(2.0f, u2)), f3_scale(2.0f, u3)), u4);
+    return f3_sub(pos, f3_div(f3_scale(dt, sum), 6.0f));
+}
+
+/* Solver.cu:163-169 */
+static f3 MacCormack(const float* ux, const float* uy, const float* uz, f3 pos, float dt,
+                     int nx, int ny, int nz)
+{
+    f3 coord_predict = RK4(ux, uy, uz, pos, dt, nx, ny, nz);
+    f3 coord_reflect = RK4(ux, uy, uz, coord_predict, -dt, nx, ny, nz);
+    return f3_add(coord_predict, f3_div(f3_sub(pos, coord_reflect), 2.f));
+}
+
+/* ------------------------------------------------------------------ kernels */
+
+float fso_trilerp(const float* field, float px, float py, float pz, float ox, float oy,
+                  float oz, int dx, int dy, int dz, int clamp)
+{
+    return trilerp(field, mk_f3(px, py, pz), ox, oy, oz, mk_i3(dx, dy, dz), clamp);
+}
+
+void fso_backtrace(const float* ux, const float* uy, const float* uz, float px, float py,
+                   float pz, float dt, int nx, int ny, int nz, int scheme, float* out3)
+{
+    f3 c = scheme == FSO_SCHEME_MACCORMACK
+               ? MacCormack(ux, uy, uz, mk_f3(px, py, pz), dt, nx, ny, nz)
+               : RK4(ux, uy, uz, mk_f3(px, py, pz), dt, nx, ny, nz);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+
+/* Solver.cu:285-293 */
+void fso_grid_init(float* temperature, float temperature_env, int nx, int ny, int nz)
+{
+    size_t n = (size_t)nx * ny * nz;
+    for (size_t q = 0; q < n; ++q) temperature[q] = temperature_env;
+}
+
+/* Solver.cu:295-307; launch (ny,nz) x nx (:1028) */
+void fso_source(float source_x, float source_y, float source_z, float radius, float* rho,
+                float* temperature, float rho0, float temperature0, int nx, int ny, int nz)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * ny;
+                /* pow(v, 2) of exactly representable v: the square is exact */
+                float ddx = (float)i - source_x, ddy = (float)j - source_y,
+                      ddz = (float)k - source_z;
+                if (ddx * ddx + ddy * ddy + ddz * ddz <= radius * radius) {
+                    rho[ind] = rho0;
+                    temperature[ind] = temperature0;
+                }
+            }
+}
+
+/* Solver.cu:346-368 with BURST 0; launch (ny+1,nz) x nx (:1031) */
+void fso_force_uy(float* uy, const float* temperature_field, float dt, float temperature_env,
+                  int nx, int ny, int nz)
+{
+    i3 max_pos = mk_i3(nx, ny, nz);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny + 1; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * (ny + 1);
+                f3 pos = mk_f3((float)i + 0.5f, (float)j, (float)k + 0.5f);
+                float temperature = trilerp(temperature_field, pos, 0.5f, 0.5f, 0.5f, max_pos, 1);
+                float buoyancy = (temperature - temperature_env) * dt;
+                uy[ind] += buoyancy;
+            }
+}
+
+/* Solver.cu:370-403 for dir in 0..3 */
+void fso_semilag(const float* field, float* new_field, const float* ux, const float* uy,
+                 const float* uz, float dt, int nx, int ny, int nz, int dir, int scheme)
+{
+    int dx = dir == 1 ? nx + 1 : nx;
+    int dy = dir == 2 ? ny + 1 : ny;
+    int dz = dir == 3 ? nz + 1 : nz;
+    float ox = dir == 1 ? 0.f : 0.5f;
+    float oy = dir == 2 ? 0.f : 0.5f;
+    float oz = dir == 3 ? 0.f : 0.5f;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+    for (int k = 0; k < dz; ++k)
+        for (int j = 0; j < dy; ++j)
+            for (int i = 0; i < dx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * dx + (size_t)k * dx * dy;
+                f3 pos = mk_f3((float)i + ox, (float)j + oy, (float)k + oz);     /* :381-383 */
+                f3 coord = scheme == FSO_SCHEME_MACCORMACK
+                               ? MacCormack(ux, uy, uz, pos, dt, nx, ny, nz)     /* :394 */
+                               : RK4(ux, uy, uz, pos, dt, nx, ny, nz);           /* :396 */
+                new_field[ind] = trilerp(field, coord, ox, oy, oz, mk_i3(dx, dy, dz), 0); /* :399 */
+            }
+}
+
+/* Solver.cu:406-423 */
+void fso_divergence(float* div_field, const float* ux, const float* uy, const float* uz,
+                    int nx, int ny, int nz)
+{
+    i3 mux = mk_i3(nx + 1, ny, nz), muy = mk_i3(nx, ny + 1, nz), muz = mk_i3(nx, ny, nz + 1);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * ny;
+                float ul = sample(ux, mk_i3(i, j, k), mux);
+                float ur = sample(ux, mk_i3(i + 1, j, k), mux);
+                float ubo = sample(uy, mk_i3(i, j, k), muy);
+                float ut = sample(uy, mk_i3(i, j + 1, k), muy);
+                float ubh = sample(uz, mk_i3(i, j, k), muz);
+                float uf = sample(uz, mk_i3(i, j, k + 1), muz);
+                float div = ur + uf + ut - ul - ubh - ubo;                        /* :420 */
+                div_field[ind] = div;
+            }
+}
+
+/* Solver.cu:426-443 -- one sweep; r may be NULL (the residual field is optional) */
+void fso_jacobi(const float* field, float* new_field, const float* div_field, float* r,
+                int nx, int ny, int nz)
+{
+    i3 max_pos = mk_i3(nx, ny, nz);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * ny;
+                float pl = sample(field, mk_i3(i - 1, j, k), max_pos);
+                float pr = sample(field, mk_i3(i + 1, j, k), max_pos);
+                float pbo = sample(field, mk_i3(i, j - 1, k), max_pos);
+                float pt = sample(field, mk_i3(i, j + 1, k), max_pos);
+                float pbh = sample(field, mk_i3(i, j, k - 1), max_pos);
+                float pf = sample(field, mk_i3(i, j, k + 1), max_pos);
+                float div = sample(div_field, mk_i3(i, j, k), max_pos);
+                new_field[ind] = (pl + pr + pbh + pf + pbo + pt - div) / 6.f;     /* :441 */
+                if (r)
+                    r[ind] = div + 6 * field[ind] - pl - pr - pbh - pf - pbo - pt; /* :442 */
+            }
+}
+
+/* Solver.cu:446-483 -- the three gradient kernels, in call order :1111-1113 */
+void fso_gradient(float* ux, float* uy, float* uz, const float* pressure, int nx, int ny, int nz)
+{
+    i3 max_pos = mk_i3(nx, ny, nz);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx + 1; ++i) {
+                size_t ind = (size_t)i + (size_t)j * (nx + 1) + (size_t)k * (nx + 1) * ny;
+                float pl = sample(pressure, mk_i3(i - 1, j, k), max_pos);
+                float pr = sample(pressure, mk_i3(i, j, k), max_pos);
+                ux[ind] -= pr - pl;                                               /* :456 */
+            }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny + 1; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * (ny + 1);
+                float pbo = sample(pressure, mk_i3(i, j - 1, k), max_pos);
+                float pt = sample(pressure, mk_i3(i, j, k), max_pos);
+                uy[ind] -= pt - pbo;                                              /* :469 */
+            }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz + 1; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * ny;
+                float pbh = sample(pressure, mk_i3(i, j, k - 1), max_pos);
+                float pf = sample(pressure, mk_i3(i, j, k), max_pos);
+                uz[ind] -= pf - pbh;                                              /* :482 */
+            }
+}
+
+/* What Solver.cu:1185-1187 (Mul + Reduce) is meant to produce: sum of r*r over the grid.
+   The reference's fp32 tree drops elements at most sizes and races in place, so the
+   defined target is the mathematically plain sum, accumulated in binary64. */
+double fso_sum_sq(const float* r, size_t n)
+{
+    double s = 0.0;
+    for (size_t q = 0; q < n; ++q) s += (double)r[q] * (double)r[q];
+    return s;
+}
+
+/* --------------------------------------------------------------- whole step */
+
+struct fso_state {
+    fso_params p;
+    float *ux, *uy, *uz, *new_ux, *new_uy, *new_uz;
+    float *rho, *new_rho, *temperature, *new_temperature;
+    float *pressure, *new_pressure, *div, *r;
+    int frame;
+};
+
+void fso_default_params(fso_params* p, int nx, int ny, int nz)
+{
+    memset(p, 0, sizeof(*p));
+    p->nx = nx; p->ny = ny; p->nz = nz;          /* Solver.h:58-60 */
+    p->rho0 = 0.1f;                              /* Solver.h:62 */
+    p->temperature0 = 2.f;                       /* Solver.h:64 */
+    p->temperature_env = 0.f;                    /* Solver.h:65 */
+    p->jacobi_iters = 30;                        /* Solver.h:68 max_iter */
+    p->dt = 0.2f;                                /* Solver.h:71 */
+    p->source_x = nx / 2.f;                      /* Solver.h:78 */
+    p->source_y = 10.f;                          /* Solver.h:79 */
+    p->source_z = nz / 2.f;                      /* Solver.h:80 */
+    p->source_radius = 7.0f;                     /* Solver.h:81 */
+    p->scheme = FSO_SCHEME_MACCORMACK;           /* Solver.cu:11 */
+}
+
+static float* zalloc(size_t n) { return (float*)calloc(n ? n : 1, sizeof(float)); }
+
+/* Solver.cu:1116-1130 + 879-952 (only the arrays the Jacobi path touches) + 993-995 */
+fso_state* fso_create(const fso_params* p)
+{
+    fso_state* s = (fso_state*)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    s->p = *p;
+    size_t nx = p->nx, ny = p->ny, nz = p->nz, n = nx * ny * nz;
+    s->ux = zalloc((nx + 1) * ny * nz);  s->new_ux = zalloc((nx + 1) * ny * nz);
+    s->uy = zalloc(nx * (ny + 1) * nz);  s->new_uy = zalloc(nx * (ny + 1) * nz);
+    s->uz = zalloc(nx * ny * (nz + 1));  s->new_uz = zalloc(nx * ny * (nz + 1));
+    s->rho = zalloc(n);          s->new_rho = zalloc(n);
+    s->temperature = zalloc(n);  s->new_temperature = zalloc(n);
+    s->pressure = zalloc(n);     s->new_pressure = zalloc(n);
+    s->div = zalloc(n);          s->r = zalloc(n);
+    fso_grid_init(s->temperature, p->temperature_env, p->nx, p->ny, p->nz);
+    return s;
+}
+
+void fso_destroy(fso_state* s)
+{
+    if (!s) return;
+    free(s->ux); free(s->uy); free(s->uz); free(s->new_ux); free(s->new_uy); free(s->new_uz);
+    free(s->rho); free(s->new_rho); free(s->temperature); free(s->new_temperature);
+    free(s->pressure); free(s->new_pressure); free(s->div); free(s->r);
+    free(s);
+}
+
+static void swapp(float** a, float** b) { float* t = *a; *a = *b; *b = t; }   /* :181-186 */
+
+void fso_stage_source(fso_state* s)
+{
+    const fso_params* p = &s->p;
+    fso_source(p->source_x, p->source_y, p->source_z, p->source_radius, s->rho, s->temperature,
+               p->rho0, p->temperature0, p->nx, p->ny, p->nz);                  /* :1028 */
+}
+
+void fso_stage_force(fso_state* s)
+{
+    const fso_params* p = &s->p;
+    fso_force_uy(s->uy, s->temperature, p->dt, p->temperature_env, p->nx, p->ny, p->nz); /* :1031 */
+}
+
+/* Solver.cu:1145-1165 */
+void fso_stage_advect(fso_state* s)
+{
+    const fso_params* p = &s->p;
+    int nx = p->nx, ny = p->ny, nz = p->nz, sc = p->scheme;
+    fso_semilag(s->ux, s->new_ux, s->ux, s->uy, s->uz, p->dt, nx, ny, nz, 1, sc);
+    fso_semilag(s->uy, s->new_uy, s->ux, s->uy, s->uz, p->dt, nx, ny, nz, 2, sc);
+    fso_semilag(s->uz, s->new_uz, s->ux, s->uy, s->uz, p->dt, nx, ny, nz, 3, sc);
+    swapp(&s->ux, &s->new_ux);
+    swapp(&s->uy, &s->new_uy);
+    swapp(&s->uz, &s->new_uz);
+    fso_semilag(s->temperature, s->new_temperature, s->ux, s->uy, s->uz, p->dt, nx, ny, nz, 0, sc);
+    swapp(&s->temperature, &s->new_temperature);
+    fso_semilag(s->rho, s->new_rho, s->ux, s->uy, s->uz, p->dt, nx, ny, nz, 0, sc);
+    swapp(&s->rho, &s->new_rho);
+}
+
+/* Solver.cu:1168-1189, the `#if 0` Jacobi branch without the per-sweep print */
+void fso_stage_project(fso_state* s)
+{
+    const fso_params* p = &s->p;
+    fso_divergence(s->div, s->ux, s->uy, s->uz, p->nx, p->ny, p->nz);          /* :1176 */
+    for (int i = 0; i < p->jacobi_iters; ++i) {
+        fso_jacobi(s->pressure, s->new_pressure, s->div, s->r, p->nx, p->ny, p->nz); /* :1182 */
+        swapp(&s->pressure, &s->new_pressure);                                 /* :1183 */
+    }
+}
+
+void fso_stage_gradient(fso_state* s)
+{
+    const fso_params* p = &s->p;
+    fso_gradient(s->ux, s->uy, s->uz, s->pressure, p->nx, p->ny, p->nz);       /* :1111-1113 */
+}
+
+/* Solver.cu:1009-1114 with VORT_CONFINE/IVOCK/REFLECT/BURST all 0, then :1136 */
+void fso_step(fso_state* s)
+{
+    fso_stage_source(s);
+    fso_stage_force(s);
+    fso_stage_advect(s);
+    fso_stage_project(s);
+    fso_stage_gradient(s);
+    s->frame++;
+}
+
+float* fso_field(fso_state* s, int which)
+{
+    switch (which) {
+    case FSO_UX: return s->ux;
+    case FSO_UY: return s->uy;
+    case FSO_UZ: return s->uz;
+    case FSO_RHO: return s->rho;
+    case FSO_T: return s->temperature;
+    case FSO_P: return s->pressure;
+    case FSO_DIV: return s->div;
+    case FSO_R: return s->r;
+    default: return NULL;
+    }
+}
+
+size_t fso_field_size(const fso_state* s, int which)
+{
+    size_t nx = s->p.nx, ny = s->p.ny, nz = s->p.nz;
+    switch (which) {
+    case FSO_UX: return (nx + 1) * ny * nz;
+    case FSO_UY: return nx * (ny + 1) * nz;
+    case FSO_UZ: return nx * ny * (nz + 1);
+    case FSO_RHO: case FSO_T: case FSO_P: case FSO_DIV: case FSO_R: return nx * ny * nz;
+    default: return 0;
+    }
+}
+
+/* residual of the LAST sweep's input iterate, as :442 leaves it in r */
+double fso_residual(const fso_state* s)
+{
+    return fso_sum_sq(s->r, (size_t)s->p.nx * s->p.ny * s->p.nz);
+}
+
+int fso_frame(const fso_state* s) { return s->frame; }

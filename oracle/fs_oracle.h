@@ -1,0 +1,65 @@
+/*
+ * fs_oracle.h -- interface of the CPU restatement in fs_oracle.c.
+ * TEST INFRASTRUCTURE ONLY: used by tests/, the smoke check and bench.py's
+ * cpu_baseline leg; never by the shipped library.
+ */
+#ifndef FS_ORACLE_H
+#define FS_ORACLE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { FSO_SCHEME_RK4 = 0, FSO_SCHEME_MACCORMACK = 1 };
+enum { FSO_UX = 0, FSO_UY = 1, FSO_UZ = 2, FSO_RHO = 3, FSO_T = 4, FSO_P = 5, FSO_DIV = 6, FSO_R = 7 };
+
+typedef struct fso_params {
+    int nx, ny, nz;
+    float dt;
+    int jacobi_iters;
+    int scheme;
+    float source_x, source_y, source_z, source_radius;
+    float rho0, temperature0, temperature_env;
+} fso_params;
+
+typedef struct fso_state fso_state;
+
+void fso_default_params(fso_params* p, int nx, int ny, int nz);
+fso_state* fso_create(const fso_params* p);
+void fso_destroy(fso_state* s);
+void fso_step(fso_state* s);
+void fso_stage_source(fso_state* s);
+void fso_stage_force(fso_state* s);
+void fso_stage_advect(fso_state* s);
+void fso_stage_project(fso_state* s);
+void fso_stage_gradient(fso_state* s);
+float* fso_field(fso_state* s, int which);
+size_t fso_field_size(const fso_state* s, int which);
+double fso_residual(const fso_state* s);
+int fso_frame(const fso_state* s);
+
+/* kernel-level entry points (known-answer tests, per-kernel parity) */
+float fso_trilerp(const float* field, float px, float py, float pz, float ox, float oy,
+                  float oz, int dx, int dy, int dz, int clamp);
+void fso_backtrace(const float* ux, const float* uy, const float* uz, float px, float py,
+                   float pz, float dt, int nx, int ny, int nz, int scheme, float* out3);
+void fso_grid_init(float* temperature, float temperature_env, int nx, int ny, int nz);
+void fso_source(float source_x, float source_y, float source_z, float radius, float* rho,
+                float* temperature, float rho0, float temperature0, int nx, int ny, int nz);
+void fso_force_uy(float* uy, const float* temperature_field, float dt, float temperature_env,
+                  int nx, int ny, int nz);
+void fso_semilag(const float* field, float* new_field, const float* ux, const float* uy,
+                 const float* uz, float dt, int nx, int ny, int nz, int dir, int scheme);
+void fso_divergence(float* div_field, const float* ux, const float* uy, const float* uz,
+                    int nx, int ny, int nz);
+void fso_jacobi(const float* field, float* new_field, const float* div_field, float* r,
+                int nx, int ny, int nz);
+void fso_gradient(float* ux, float* uy, float* uz, const float* pressure, int nx, int ny, int nz);
+double fso_sum_sq(const float* r, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
