@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cell-updates/s of the full simulation step on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--iters 80]
+
+One step = source -> buoyancy -> advect (ux, uy, uz, T, rho) -> divergence ->
+`iters` Jacobi sweeps -> pressure-gradient subtraction, on synthetic input (all-zero
+initial state, sphere source stamped every step; no RNG).  At N = 1 the workload is the
+512^3 / 80-sweep configuration (the size whose Jacobi working set does not fit the
+256 MiB Infinity Cache).  For N > 1 (launched by torch.distributed.run, one rank per
+GPU) the grid is the weak-scaling column 512 x 512 x (512*N), z-slab decomposed.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel class of the
+step, timed with HIP events on the solver's own stream inside the timed region;
+`cpu_baseline` is the CPU oracle (a restatement of the reference's loops, there is no
+CPU path upstream) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+# algorithmic (compulsory) bytes per cell, fp32: each kernel reads every input once and
+# writes every output once
+BYTES_PER_CELL = {
+    "force": 12.0,             # read T, read+write uy
+    "advect_velocity": 48.0,   # 3 x (3 reads + 1 write)
+    "advect_scalars": 40.0,    # 2 x (4 reads + 1 write)
+    "divergence": 16.0,        # 3 reads + 1 write
+    "jacobi": 12.0,            # per sweep: read p, read div, write p'
+    "gradient": 28.0,          # read p, read+write 3 velocity components
+}
+
+
+def step_bytes_per_cell(iters):
+    return 144.0 + 12.0 * iters
+
+
+def cpu_baseline(iters, sample_n):
+    """Oracle timed on the host cores: one step of sample_n^3 with the same sweep count."""
+    import oracle
+    oracle.build()
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    warm = oracle.Oracle(oracle.default_params(32, 32, 32, jacobi_iters=4))
+    warm.step()
+    warm.close()
+    o = oracle.Oracle(oracle.default_params(sample_n, sample_n, sample_n, jacobi_iters=iters))
+    o.step()   # first step also pays first-touch page faults: leave it untimed
+    t0 = time.perf_counter()
+    o.step()
+    dt = time.perf_counter() - t0
+    o.close()
+    return {
+        "value": sample_n ** 3 / dt,
+        "unit": "cell-updates/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "1 step of %d^3, %d Jacobi sweeps (2nd step from the zero state), gcc -O2 "
+                  "-ffp-contract=off + OpenMP, %.2f s" % (sample_n, iters, dt),
+    }
+
+
+def load_pmc_traffic(kernel, workload):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass, if one matches."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        e = d.get(kernel, {}).get(workload)
+        return float(e["hbm_bytes_per_launch"]) if e else None
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512, help="nx = ny = per-GPU nz")
+    ap.add_argument("--iters", type=int, default=80, help="Jacobi sweeps per step")
+    ap.add_argument("--scheme", type=int, default=1)
+    ap.add_argument("--naive-jacobi", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=192)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
+                         % (args.gpus, world))
+
+    import torch
+    import fluidsolver_amd as fs
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    n = args.size
+    flags = fs.FS_FLAG_JACOBI_NAIVE if args.naive_jacobi else 0
+    if world == 1:
+        p = fs.default_params(n, n, n, jacobi_iters=args.iters, scheme=args.scheme,
+                              device=local_rank, flags=flags)
+        solver = fs.Solver(p).Initialize()
+        cells_total = n ** 3
+        workload = "%d^3 smoke plume, %d Jacobi sweeps/step, MacCormack, 1 GPU" % (n, args.iters)
+        par = "1 GPU"
+    else:
+        from fluidsolver_amd.slab import SlabSolver
+        p = fs.default_params(n, n, n * world, jacobi_iters=args.iters, scheme=args.scheme,
+                              device=local_rank, flags=flags)
+        solver = SlabSolver(p, rank, world).Initialize()
+        cells_total = n * n * n * world
+        workload = ("%dx%dx%d weak-scaling column, %d Jacobi sweeps/step, MacCormack, z-slabs on %d GPUs"
+                    % (n, n, n * world, args.iters, world))
+        par = "z-slab x%d" % world
+
+    def barrier():
+        solver.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    solver.step(args.warmup)
+    barrier()
+    solver.profile(True)
+    solver.profile_reset()
+    t0 = time.perf_counter()
+    solver.step(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = solver.profile_read()
+    solver.profile(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = cells_total * args.steps / elapsed
+        cells_rank = cells_total // world
+        # dominant kernel class by device time
+        dom = max(prof, key=lambda k: prof[k][0])
+        dom_ms, dom_launches = prof[dom]
+        if dom == "jacobi":
+            sweeps_per_launch = args.iters * args.steps / max(dom_launches, 1)
+            algo_bytes = BYTES_PER_CELL["jacobi"] * cells_rank * sweeps_per_launch
+        else:
+            # advect_velocity makes 3 launches per step; its bytes are per stage
+            algo_bytes = BYTES_PER_CELL.get(dom, 0.0) * cells_rank * args.steps / max(dom_launches, 1)
+        avg_launch_s = dom_ms / max(dom_launches, 1) * 1e-3
+        achieved = algo_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = load_pmc_traffic(dom, "%d^3" % n)
+        stage_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
+        out = {
+            "metric": "cell-updates/sec per step (incl. pressure iters)",
+            "value": value,
+            "unit": "cell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (zero initial state, sphere source every step, no RNG)",
+            "config": {"workload": workload, "nx": n, "ny": n, "nz": n * world,
+                       "jacobi_sweeps": args.iters, "parallelism": par},
+            "step_hbm_frac": step_bytes_per_cell(args.iters) * cells_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "stage_ms_per_step": stage_ms,
+            "roofline": {
+                "kernel": dom,
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "avg_launch_ms": avg_launch_s * 1e3,
+                "launches": dom_launches,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,10 @@ EXPORTED_SYMBOLS = (
     "fs_stage_jacobi", "fs_stage_project", "fs_stage_gradient", "fs_density_host",
     "fs_velocity_host", "fs_field_host", "fs_field_size", "fs_field_upload", "fs_field_device",
     "fs_residual", "fs_last_sweeps", "fs_last_error", "fs_version",
+    "fs_profile_enable", "fs_profile_read", "fs_profile_reset",
 )
+
+STAGES = ("source", "force", "advect_velocity", "advect_scalars", "divergence", "jacobi", "gradient")
 
 
 class FsError(RuntimeError):
@@ -100,6 +103,9 @@ def load_library():
     L.fs_field_upload.argtypes = [vp, C.c_int, _fp]
     L.fs_field_device.argtypes = [vp, C.c_int, C.POINTER(_fp), C.POINTER(Layout)]
     L.fs_residual.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.fs_profile_enable.argtypes = [vp, C.c_int]
+    L.fs_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.fs_profile_reset.argtypes = [vp]
     L.fs_last_error.restype = C.c_char_p
     L.fs_version.restype = C.c_char_p
     _lib = L
@@ -241,6 +247,21 @@ class Solver:
         out = C.c_double()
         self._check(self._L.fs_residual(self._handle(), which, C.byref(out)))
         return out.value
+
+    def profile(self, on=True):
+        self._check(self._L.fs_profile_enable(self._handle(), int(on)))
+
+    def profile_reset(self):
+        self._check(self._L.fs_profile_reset(self._handle()))
+
+    def profile_read(self):
+        """{stage: (device ms total, kernel launches)} since the last reset; synchronises."""
+        out = {}
+        for q, name in enumerate(STAGES):
+            ms, n = C.c_double(), C.c_longlong()
+            self._check(self._L.fs_profile_read(self._handle(), q, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
 
     @property
     def last_sweeps(self):

@@ -1,0 +1,64 @@
+// Solver.cpp -- the reference-compatible C++ class over the C ABI (include/Solver.h).
+#include "Solver.h"
+#include "fluidsolver.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+// reference error convention: print and exit(1) (CuSolver/Include/CudaUtility.h:12-23)
+void check(int rc, const char* what)
+{
+	if (rc != FS_OK) {
+		std::fprintf(stderr, "GPU error at: %s\n%s\n", what, fs_last_error());
+		std::exit(1);
+	}
+}
+}
+
+Solver::~Solver()
+{
+	if (handle) fs_destroy(handle);
+}
+
+Solver& Solver::operator=(Solver&& other) noexcept
+{
+	if (this != &other) {
+		if (handle) fs_destroy(handle);
+		handle = other.handle;
+		other.handle = nullptr;
+	}
+	return *this;
+}
+
+void Solver::Initialize()
+{
+	fs_params p;
+	check(fs_default_params(&p, Nx, Ny, Nz), "fs_default_params");
+	p.jacobi_iters = jacobi_iters;
+	check(fs_create(&p, &handle), "fs_create");
+}
+
+void Solver::Update()
+{
+	std::printf("frame: %d\n", fs_frame(handle));
+	check(fs_step(handle), "fs_step");
+}
+
+void Solver::Advect() { check(fs_stage_advect(handle), "fs_stage_advect"); }
+
+void Solver::Project() { check(fs_stage_project(handle), "fs_stage_project"); }
+
+float* Solver::GetDensityField()
+{
+	const float* p = fs_density_host(handle);
+	if (!p) check(FS_ERR_HIP, "fs_density_host");
+	return const_cast<float*>(p);
+}
+
+float* Solver::GetVelocityField(int c)
+{
+	const float* p = fs_velocity_host(handle, c);
+	if (!p) check(FS_ERR_HIP, "fs_velocity_host");
+	return const_cast<float*>(p);
+}

@@ -55,6 +55,8 @@ void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, co
 // whether the final iterate ended in np (1) or p (0).  Single-slab (no halo exchange) only.
 void jacobi_multi(hipStream_t st, const FsGrid& g, float* p, float* np, const float* div,
                   int sweeps, int naive, int* result_in_np);
+// number of kernel launches jacobi_multi makes for `sweeps` sweeps
+int jacobi_launches(const FsGrid& g, int sweeps, int naive);
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p);
 // sum over owned cells of (div + 6p - neighbours)^2 in binary64; partial must hold
 // residual_partials(g) doubles, out one double.

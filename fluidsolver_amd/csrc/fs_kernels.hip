@@ -500,6 +500,13 @@ void jacobi_multi(hipStream_t st, const FsGrid& g, float* p, float* np, const fl
     *result_in_np = (a == np) ? 1 : 0;
 }
 
+int jacobi_launches(const FsGrid& g, int sweeps, int naive)
+{
+    (void)g;
+    (void)naive;
+    return sweeps;
+}
+
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p)
 {
     ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;

@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <utility>
+#include <vector>
 
 namespace {
 
@@ -59,6 +60,13 @@ struct fs_solver {
     int* h_flag = nullptr;            // pinned
     int frame = 0;
     int last_sweeps = 0;
+    // stage timing with HIP events on the solver's own stream (fs_profile_*)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_free;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> ev_pending;
+    double prof_ms[FS_NUM_STAGES] = {};
+    long long prof_launches[FS_NUM_STAGES] = {};
 };
 
 namespace {
@@ -84,6 +92,33 @@ float** field_slot(fs_solver* s, int field)
     }
 }
 
+// Brackets one stage with a pair of events when profiling is on.
+struct StageScope {
+    fs_solver* s;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageScope(fs_solver* s_, int stage_, int launches) : s(s_), stage(stage_)
+    {
+        if (!s->profiling) return;
+        s->prof_launches[stage] += launches;
+        for (hipEvent_t* e : {&a, &b}) {
+            if (!s->ev_free.empty()) {
+                *e = s->ev_free.back();
+                s->ev_free.pop_back();
+            } else if (hipEventCreate(e) != hipSuccess) {
+                *e = nullptr;
+            }
+        }
+        if (a && b) (void)hipEventRecord(a, s->st);
+    }
+    ~StageScope()
+    {
+        if (!s->profiling || !a || !b) return;
+        (void)hipEventRecord(b, s->st);
+        s->ev_pending.push_back({stage, a, b});
+    }
+};
+
 int check_flag(fs_solver* s)
 {
     // only slabs with a non-wall z face can raise the halo flag
@@ -99,8 +134,11 @@ int run_jacobi(fs_solver* s, int sweeps)
 {
     if (sweeps <= 0) return FS_OK;
     int in_np = 0;
-    fsk::jacobi_multi(s->st, s->g, s->f.p, s->f.np, s->f.div, sweeps,
-                      (s->prm.flags & FS_FLAG_JACOBI_NAIVE) ? 1 : 0, &in_np);
+    {
+        int naive = (s->prm.flags & FS_FLAG_JACOBI_NAIVE) ? 1 : 0;
+        StageScope sc(s, FS_STAGE_JACOBI, fsk::jacobi_launches(s->g, sweeps, naive));
+        fsk::jacobi_multi(s->st, s->g, s->f.p, s->f.np, s->f.div, sweeps, naive, &in_np);
+    }
     if (in_np) std::swap(s->f.p, s->f.np);
     // After an odd number of sweeps the previous iterate sits in np, as it does after the
     // reference's per-sweep swap (Solver.cu:1183).  After an even number the blocked kernels
@@ -158,6 +196,11 @@ int fs_destroy(fs_solver* s)
     if (!s) return FS_OK;
     (void)hipSetDevice(s->device);
     if (s->st) (void)hipStreamSynchronize(s->st);
+    for (auto& pe : s->ev_pending) {
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
+    }
+    for (hipEvent_t e : s->ev_free) (void)hipEventDestroy(e);
     for (float*& h : s->host)
         if (h) (void)hipHostFree(h);
     if (s->h_res) (void)hipHostFree(s->h_res);
@@ -277,6 +320,7 @@ int fs_stage_source(fs_solver* s)
     FS_HIP(hipSetDevice(s->device));
     FsSource src{s->prm.source_x, s->prm.source_y, s->prm.source_z, s->prm.source_radius,
                  s->prm.source_rho, s->prm.source_temperature};
+    StageScope sc(s, FS_STAGE_SOURCE, 1);
     fsk::source(s->st, s->g, src, s->f.rho, s->f.T);
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -286,6 +330,7 @@ int fs_stage_force(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     FS_HIP(hipSetDevice(s->device));
+    StageScope sc(s, FS_STAGE_FORCE, 1);
     fsk::force_uy(s->st, s->g, s->f.uy, s->f.T, s->prm.dt, s->prm.temperature_env);
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -299,13 +344,17 @@ int fs_stage_advect(fs_solver* s)
     const float dt = s->prm.dt;
     const int sc = s->prm.scheme;
     // Solver.cu:1153-1158: all three components from the OLD velocity, then swap
-    fsk::advect_velocity(s->st, s->g, 1, f.ux, f.nux, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
-    fsk::advect_velocity(s->st, s->g, 2, f.uy, f.nuy, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
-    fsk::advect_velocity(s->st, s->g, 3, f.uz, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    {
+        StageScope ps(s, FS_STAGE_ADVECT_VELOCITY, 3);
+        fsk::advect_velocity(s->st, s->g, 1, f.ux, f.nux, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+        fsk::advect_velocity(s->st, s->g, 2, f.uy, f.nuy, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+        fsk::advect_velocity(s->st, s->g, 3, f.uz, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    }
     std::swap(f.ux, f.nux);
     std::swap(f.uy, f.nuy);
     std::swap(f.uz, f.nuz);
     // Solver.cu:1160-1164: T then rho with the NEW (advected, unprojected) velocity
+    StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 1);
     fsk::advect_scalars(s->st, s->g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
     std::swap(f.T, f.nT);
     std::swap(f.rho, f.nrho);
@@ -317,6 +366,7 @@ int fs_stage_divergence(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     FS_HIP(hipSetDevice(s->device));
+    StageScope sc(s, FS_STAGE_DIVERGENCE, 1);
     fsk::divergence(s->st, s->g, s->f.div, s->f.ux, s->f.uy, s->f.uz);
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -358,6 +408,7 @@ int fs_stage_gradient(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     FS_HIP(hipSetDevice(s->device));
+    StageScope sc(s, FS_STAGE_GRADIENT, 1);
     fsk::gradient(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->f.p);
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -478,6 +529,50 @@ int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layout)
         layout->ghost = s->g.ghost;
         layout->pitch = (size_t)s->g.pitch;
         layout->plane = (size_t)s->g.plane;
+    }
+    return FS_OK;
+}
+
+int fs_profile_enable(fs_solver* s, int on)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    s->profiling = on != 0;
+    return FS_OK;
+}
+
+static int drain_events(fs_solver* s)
+{
+    FS_HIP(hipSetDevice(s->device));
+    FS_HIP(hipStreamSynchronize(s->st));
+    for (auto& pe : s->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) s->prof_ms[pe.stage] += ms;
+        s->ev_free.push_back(pe.a);
+        s->ev_free.push_back(pe.b);
+    }
+    s->ev_pending.clear();
+    return FS_OK;
+}
+
+int fs_profile_read(fs_solver* s, int stage, double* ms_total, long long* launches)
+{
+    if (!s || stage < 0 || stage >= FS_NUM_STAGES)
+        return fail(FS_ERR_INVALID, "fs_profile_read: bad argument");
+    int rc = drain_events(s);
+    if (rc) return rc;
+    if (ms_total) *ms_total = s->prof_ms[stage];
+    if (launches) *launches = s->prof_launches[stage];
+    return FS_OK;
+}
+
+int fs_profile_reset(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    int rc = drain_events(s);
+    if (rc) return rc;
+    for (int q = 0; q < FS_NUM_STAGES; ++q) {
+        s->prof_ms[q] = 0.0;
+        s->prof_launches[q] = 0;
     }
     return FS_OK;
 }

@@ -1,0 +1,65 @@
+// fs_bench.cpp -- headless C++ benchmark over the C ABI only (no Python, no torch).
+//   fs_bench [n=256] [sweeps=80] [steps=20] [warmup=5] [dump_prefix]
+// Prints one JSON line: cell-updates/s and per-stage device time.  With dump_prefix, writes
+// the final rho/ux/uy/uz as raw little-endian float32, x fastest (dense reference layout).
+#include "fluidsolver.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+static void die(const char* what)
+{
+	std::fprintf(stderr, "fs_bench: %s: %s\n", what, fs_last_error());
+	std::exit(1);
+}
+
+int main(int argc, char** argv)
+{
+	int n = argc > 1 ? std::atoi(argv[1]) : 256;
+	int sweeps = argc > 2 ? std::atoi(argv[2]) : 80;
+	int steps = argc > 3 ? std::atoi(argv[3]) : 20;
+	int warmup = argc > 4 ? std::atoi(argv[4]) : 5;
+	const char* dump = argc > 5 ? argv[5] : nullptr;
+
+	fs_params p;
+	if (fs_default_params(&p, n, n, n)) die("fs_default_params");
+	p.jacobi_iters = sweeps;
+	fs_solver* s = nullptr;
+	if (fs_create(&p, &s)) die("fs_create");
+	if (fs_steps(s, warmup) || fs_sync(s)) die("warmup");
+	fs_profile_enable(s, 1);
+	fs_profile_reset(s);
+	auto t0 = std::chrono::steady_clock::now();
+	if (fs_steps(s, steps) || fs_sync(s)) die("fs_steps");
+	double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	static const char* names[FS_NUM_STAGES] = {"source", "force", "advect_velocity", "advect_scalars",
+	                                           "divergence", "jacobi", "gradient"};
+	std::printf("{\"n\": %d, \"sweeps\": %d, \"steps\": %d, \"ms_per_step\": %.4f, \"cell_updates_per_s\": %.6e, "
+	            "\"step_gbs\": %.1f, \"stage_ms_per_step\": {",
+	            n, sweeps, steps, sec / steps * 1e3, (double)n * n * n * steps / sec,
+	            (144.0 + 12.0 * sweeps) * n * n * n * steps / sec / 1e9);
+	for (int q = 0; q < FS_NUM_STAGES; ++q) {
+		double ms = 0;
+		long long launches = 0;
+		fs_profile_read(s, q, &ms, &launches);
+		std::printf("%s\"%s\": %.4f", q ? ", " : "", names[q], ms / steps);
+	}
+	std::printf("}}\n");
+	if (dump) {
+		static const char* fn[4] = {"ux", "uy", "uz", "rho"};
+		static const int ids[4] = {FS_UX, FS_UY, FS_UZ, FS_RHO};
+		for (int q = 0; q < 4; ++q) {
+			const float* h = fs_field_host(s, ids[q]);
+			if (!h) die("fs_field_host");
+			std::string path = std::string(dump) + "_" + fn[q] + ".f32";
+			FILE* f = std::fopen(path.c_str(), "wb");
+			if (!f) { std::perror(path.c_str()); return 1; }
+			std::fwrite(h, sizeof(float), fs_field_size(s, ids[q]), f);
+			std::fclose(f);
+		}
+	}
+	fs_destroy(s);
+	return 0;
+}

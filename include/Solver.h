@@ -1,0 +1,68 @@
+/*
+ * Solver.h -- source-compatible stand-in for the reference's CuSolver/Include/Solver.h,
+ * so that the Renderer (Renderer/Source/FluidSolver.cpp:152-156, 210-213; main.cpp:11,17)
+ * and the headless programs compile and link against the gfx950 library unchanged.
+ *
+ * Same public names and meaning as the reference class (Solver.h:13-44):
+ *   Solver(), ~Solver(), Initialize(), Update(), Advect(), Project(), GetDensityField(),
+ * plus velocity access, which the reference lacks.  The object holds ONE pointer (the
+ * C-ABI handle of include/fluidsolver.h), so constructing it by value on the caller's
+ * stack, as the Renderer does, does not depend on the library's internals.
+ *
+ * Error behaviour is the reference's (CudaUtility.h:12-23): a failed GPU call prints the
+ * error to stderr and exits with status 1.
+ */
+#pragma once
+
+#if defined(_WIN32)
+#ifdef SOLVER_EXPORTS
+#define SOLVER_API __declspec(dllexport)
+#else
+#define SOLVER_API __declspec(dllimport)
+#endif
+#else
+#define SOLVER_API __attribute__((visibility("default")))
+#endif
+
+/* compile-time grid of the reference (Solver.h:9-11); override with -DNx=.. etc. */
+#ifndef Nx
+#define Nx 64
+#endif
+#ifndef Ny
+#define Ny 128
+#endif
+#ifndef Nz
+#define Nz 64
+#endif
+
+struct fs_solver;
+
+class SOLVER_API Solver
+{
+public:
+	Solver() {}
+	~Solver();
+	Solver(Solver&& other) noexcept : handle(other.handle) { other.handle = nullptr; }
+	Solver& operator=(Solver&& other) noexcept;
+	Solver(const Solver&) = delete;
+	Solver& operator=(const Solver&) = delete;
+
+	/* allocate + zero all fields, T = T_env (reference Solver.cu:1116-1130) */
+	void Initialize();
+	/* one simulation step; prints "frame: N" like the reference (Solver.cu:1132-1137) */
+	void Update();
+	/* the two sub-steps the reference also exposes publicly (Solver.h:24,26) */
+	void Advect();
+	void Project();
+	/* blocking copy of the density field into a solver-owned host buffer of
+	   Nx*Ny*Nz floats, x fastest (Solver.cu:1368-1372); valid until the next call */
+	float* GetDensityField();
+	/* new: velocity component c = 0,1,2 -> ux (Nx+1,Ny,Nz), uy (Nx,Ny+1,Nz), uz (Nx,Ny,Nz+1) */
+	float* GetVelocityField(int c);
+	/* new: number of Jacobi sweeps per step (reference max_iter, Solver.h:68); call before Initialize */
+	void SetJacobiIterations(int iters) { jacobi_iters = iters; }
+
+private:
+	fs_solver* handle = nullptr;
+	int jacobi_iters = 30;
+};

@@ -139,6 +139,19 @@ FS_API int fs_residual(fs_solver* s, int which, double* out);
 /* sweeps the last fs_step / fs_stage_project actually ran (convergence mode) */
 FS_API int fs_last_sweeps(const fs_solver* s);
 
+/* -- stage timing (no counterpart in the reference, which only prints fps,
+      Renderer/Source/FluidSolver.cpp:179): when enabled, every stage is bracketed by a
+      pair of HIP events on the solver's own stream.  fs_profile_read synchronises and
+      returns the accumulated device time of a stage and the number of kernel launches
+      it made, so  ms_total / launches  is the average launch duration. -- */
+enum {
+    FS_STAGE_SOURCE = 0, FS_STAGE_FORCE, FS_STAGE_ADVECT_VELOCITY, FS_STAGE_ADVECT_SCALARS,
+    FS_STAGE_DIVERGENCE, FS_STAGE_JACOBI, FS_STAGE_GRADIENT, FS_NUM_STAGES
+};
+FS_API int fs_profile_enable(fs_solver* s, int on);
+FS_API int fs_profile_read(fs_solver* s, int stage, double* ms_total, long long* launches);
+FS_API int fs_profile_reset(fs_solver* s);
+
 FS_API const char* fs_last_error(void);
 FS_API const char* fs_version(void);
 
