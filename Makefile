@@ -3,7 +3,7 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: the kernels must round exactly like an uncontracted host build.
-HIPFLAGS ?= -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
+HIPFLAGS ?= -O3 --offload-arch=$(ARCH) -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 -Wall -Wno-unused-function
 CXX      ?= g++
 CXXFLAGS ?= -O2 -std=c++17 -fPIC -Wall
 
@@ -21,10 +21,13 @@ $(LIBDIR) $(BINDIR):
 $(LIBDIR)/fs_kernels.o: $(CSRC)/fs_kernels.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(LIBDIR)/fs_jacobi.o: $(CSRC)/fs_jacobi.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(LIBDIR)/fs_solver.o: $(CSRC)/fs_solver.hip $(CSRC)/fs_kernels.h include/fluidsolver.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(LIBDIR)/fs_kernels.o $(LIBDIR)/fs_solver.o
+$(LIB): $(LIBDIR)/fs_kernels.o $(LIBDIR)/fs_jacobi.o $(LIBDIR)/fs_solver.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -Wl,-rpath,/opt/rocm/lib -Wl,-soname,libfluidsolver.so
 
 $(SHIM): $(CSRC)/Solver.cpp include/Solver.h include/fluidsolver.h $(LIB)

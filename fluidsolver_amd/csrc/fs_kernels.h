@@ -52,9 +52,11 @@ void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, co
 void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
                   int zb, int ze);
 // `sweeps` Jacobi sweeps with temporal blocking where it pays; returns through *result_in_np
-// whether the final iterate ended in np (1) or p (0).  Single-slab (no halo exchange) only.
+// whether the final iterate ended in np (1) or p (0), and through *prev_held whether the other
+// buffer holds the iterate before the last sweep (true iff the last launch was a single sweep).
+// Single-slab (no halo exchange) only.
 void jacobi_multi(hipStream_t st, const FsGrid& g, float* p, float* np, const float* div,
-                  int sweeps, int naive, int* result_in_np);
+                  int sweeps, int naive, int* result_in_np, int* prev_held);
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
 int jacobi_launches(const FsGrid& g, int sweeps, int naive);
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p);

@@ -287,27 +287,6 @@ __global__ void k_divergence(float* __restrict__ div, const float* __restrict__ 
     div[o] = ur + uf + ut - ul - ubh - ubo;
 }
 
-// Solver.cu:426-443, one sweep.  p/np/div are pre-offset for global z; neighbours are
-// clamped at the six global walls only (slab-internal faces read ghost planes).
-__global__ void k_jacobi(const float* __restrict__ p, float* __restrict__ np,
-                         const float* __restrict__ div, int nx, int ny, int nz, int pitch, int plane,
-                         int zb)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y * blockDim.y + threadIdx.y;
-    int z = zb + blockIdx.z;
-    if (x >= nx || y >= ny) return;
-    int o = x + y * pitch + z * plane;
-    float pl = p[x > 0 ? o - 1 : o];
-    float pr = p[x < nx - 1 ? o + 1 : o];
-    float pbo = p[y > 0 ? o - pitch : o];
-    float pt = p[y < ny - 1 ? o + pitch : o];
-    float pbh = p[z > 0 ? o - plane : o];
-    float pf = p[z < nz - 1 ? o + plane : o];
-    float d = div[o];
-    np[o] = (pl + pr + pbh + pf + pbo + pt - d) / 6.f;
-}
-
 // Solver.cu:446-483, the three kernels fused: thread (i,j,k) owns face i of ux, face j of
 // uy and face k of uz where those exist.  Wall faces see two equal clamped samples and
 // subtract exactly 0.
@@ -477,34 +456,6 @@ void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, co
 {
     hipLaunchKernelGGL(k_divergence, tile_grid(g.nx, g.ny, g.nzl), kTile, 0, st, div, ux, uy, uz,
                        g.nx, g.ny, g.pitch, g.plane);
-}
-
-void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
-                  int zb, int ze)
-{
-    if (ze <= zb) return;
-    ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
-    hipLaunchKernelGGL(k_jacobi, tile_grid(g.nx, g.ny, ze - zb), kTile, 0, st, p - zoff, np - zoff,
-                       div - zoff, g.nx, g.ny, g.nz, g.pitch, g.plane, zb);
-}
-
-void jacobi_multi(hipStream_t st, const FsGrid& g, float* p, float* np, const float* div,
-                  int sweeps, int naive, int* result_in_np)
-{
-    (void)naive;
-    float *a = p, *b = np;
-    for (int s = 0; s < sweeps; ++s) {
-        jacobi_sweep(st, g, a, b, div, g.z0, g.z0 + g.nzl);
-        float* t = a; a = b; b = t;
-    }
-    *result_in_np = (a == np) ? 1 : 0;
-}
-
-int jacobi_launches(const FsGrid& g, int sweeps, int naive)
-{
-    (void)g;
-    (void)naive;
-    return sweeps;
 }
 
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p)

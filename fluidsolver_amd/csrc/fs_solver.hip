@@ -60,6 +60,7 @@ struct fs_solver {
     int* h_flag = nullptr;            // pinned
     int frame = 0;
     int last_sweeps = 0;
+    bool prev_held = false;           // np holds the iterate before the last sweep
     // stage timing with HIP events on the solver's own stream (fs_profile_*)
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
@@ -137,12 +138,11 @@ int run_jacobi(fs_solver* s, int sweeps)
     {
         int naive = (s->prm.flags & FS_FLAG_JACOBI_NAIVE) ? 1 : 0;
         StageScope sc(s, FS_STAGE_JACOBI, fsk::jacobi_launches(s->g, sweeps, naive));
-        fsk::jacobi_multi(s->st, s->g, s->f.p, s->f.np, s->f.div, sweeps, naive, &in_np);
+        int held = 0;
+        fsk::jacobi_multi(s->st, s->g, s->f.p, s->f.np, s->f.div, sweeps, naive, &in_np, &held);
+        s->prev_held = held != 0;
     }
     if (in_np) std::swap(s->f.p, s->f.np);
-    // After an odd number of sweeps the previous iterate sits in np, as it does after the
-    // reference's per-sweep swap (Solver.cu:1183).  After an even number the blocked kernels
-    // may have used np as scratch; fs_residual(which=1) documents that.
     s->last_sweeps += sweeps;
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -581,6 +581,9 @@ int fs_residual(fs_solver* s, int which, double* out)
 {
     if (!s || !out || (which != 0 && which != 1))
         return fail(FS_ERR_INVALID, "fs_residual: bad argument");
+    if (which == 1 && !s->prev_held)
+        return fail(FS_ERR_STATE, "fs_residual: the iterate before the last sweep is not held "
+                                  "(the last sweeps ran as one fused multi-sweep pass)");
     FS_HIP(hipSetDevice(s->device));
     return residual_sync(s, which == 0 ? s->f.p : s->f.np, out);
 }

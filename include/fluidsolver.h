@@ -134,7 +134,9 @@ FS_API int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layo
       sum over the grid of r^2 with r = div + 6p - sum(neighbours) (Solver.cu:442),
       accumulated in binary64.  which = 0: r of the current pressure;
       which = 1: r of the input iterate of the last sweep (what the reference's r
-      array holds after its loop). -- */
+      array holds after its loop); available only while that iterate is still held,
+      i.e. when the last sweep ran on its own (sweep count not a multiple of 4, or
+      FS_FLAG_JACOBI_NAIVE), else FS_ERR_STATE. -- */
 FS_API int fs_residual(fs_solver* s, int which, double* out);
 /* sweeps the last fs_step / fs_stage_project actually ran (convergence mode) */
 FS_API int fs_last_sweeps(const fs_solver* s);
