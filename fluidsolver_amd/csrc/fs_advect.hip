@@ -1,0 +1,612 @@
+// fs_advect.hip -- semi-Lagrangian advection for gfx950.
+//
+// Reference expressions restated here (CuSolver/Source/Solver.cu): zero-outside point sample
+// :37-42, trilinear gather :52-113, RK4 :139-161, MacCormack :163-169, SemiLagKernel :370-403,
+// Advect :1145-1165.  Arithmetic is binary32 in the reference's association order without
+// FMA contraction.
+//
+// One output element costs 24 velocity gathers (MacCormack = 2 x RK4 = 8 stages x 3 staggered
+// components) and one field gather, 8 taps each.  Measured on MI355X the limiter is not HBM but
+// the CU's vector-memory address path (a wave-wide dword load holds it for ~4-7 cycles, a
+// dwordx2 for ~15) and then the VALU.  So the velocity gathers are served from LDS: a workgroup
+// stages the zero-extended velocity brick around its outputs (halo kHalo cells) once, and every
+// gather whose 8 taps fall inside the brick reads LDS (ds_read2_b32 pairs, ~4 cycles per pair);
+// the rare gather that leaves the brick takes the global path below, which returns the same
+// values.  The three velocity components are advected by one kernel so they share the brick.
+#include "fs_kernels.h"
+
+#include <climits>
+#include <cstdlib>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct Axis {
+    int i;     // lower tap index
+    float f;   // interpolation weight of the upper tap
+};
+
+// Integer/fraction split of one gather coordinate, Solver.cu:58-82.  The reference
+// compares the float against the double literal -1e-6; no float lies between that
+// literal and its float rounding (-1e-6f is the nearer-to-zero neighbour), so the float
+// comparison below decides identically for every float input.
+__device__ __forceinline__ Axis split_axis(float x)
+{
+    int ix = (int)x;                 // truncation toward zero
+    float fx = x - floorf(x);
+    if (x < -1e-6f) {
+        ix -= 1;
+        fx = x - (float)ix;
+    }
+    return Axis{ix, fx};
+}
+
+// Math.cuh:57-60
+__device__ __forceinline__ float lerp1(float a, float b, float s)
+{
+    return a * (1.0f - s) + b * s;
+}
+
+// Solver.cu:109-112
+__device__ __forceinline__ float trilerp8(float a, float b, float c, float d, float e, float f,
+                                          float g, float h, float fx, float fy, float fz)
+{
+    float l1 = lerp1(lerp1(a, b, fx), lerp1(c, d, fx), fy);
+    float l2 = lerp1(lerp1(e, f, fx), lerp1(g, h, fx), fy);
+    return lerp1(l1, l2, fz);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi)
+{
+    return min(max(v, lo), hi);
+}
+
+// Limits of the lower tap index along z for a gather on this slab.
+struct ZRange {
+    int lo, hi;          // clamp range of the lower tap
+    int chk_lo, chk_hi;  // a lower tap outside [chk_lo, chk_hi] left the ghost planes
+};
+
+// One gathered array on the global path: a raw buffer resource whose base is the lowest
+// element any clamped tap can reach, and the constant that turns (ix, iy, iz) into a
+// non-negative byte offset from it.
+struct Fld {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned c;
+};
+
+__device__ __forceinline__ Fld make_fld(const float* f, const ZRange& zr, int pitch, int plane)
+{
+    // f is pre-offset so that global z indexes it directly; clamped taps reach
+    // x, y in [-2, extent + 1] and z in [zr.lo, zr.hi + 1]
+    long low = (long)zr.lo * plane - 2 * pitch - 2;
+    unsigned bytes = ((unsigned)(zr.hi + 2 - zr.lo) * (unsigned)plane + 2u * pitch + 4u) * 4u;
+    Fld F;
+    F.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f + low), 0, bytes, 0x00020000);
+    F.c = 8u + 8u * (unsigned)pitch - 4u * (unsigned)zr.lo * (unsigned)plane;
+    return F;
+}
+
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, soff, 0));
+}
+
+// Zero-outside trilinear gather (Solver.cu:52-113 with b_minmax_sampe = false) from global
+// memory on the padded layout: clamping the lower tap to [-2, extent] lands every outside tap on
+// a stored zero.  Eight dword buffer loads share one per-lane offset (row / plane steps ride in
+// the scalar offset); the x+1 taps get their own offset register, hidden from the load combiner,
+// because a dwordx2 costs the address path ~2x two dwords.
+__device__ __forceinline__ float gather_global(const Fld& F, Axis ax, Axis ay, Axis az, int dx,
+                                               int dy, const ZRange& zr, int pitch, int plane)
+{
+    int ix = clampi(ax.i, -2, dx);
+    int iy = clampi(ay.i, -2, dy);
+    int iz = clampi(az.i, zr.lo, zr.hi);
+    const int sp = pitch * 4, sq = plane * 4;
+    unsigned vo = F.c + (unsigned)(ix * 4) + (unsigned)(iy * sp) + (unsigned)(iz * sq);
+    unsigned vo1 = vo + 4u;
+    asm volatile("" : "+v"(vo1));
+    float a = bload(F.rs, vo, 0);
+    float b = bload(F.rs, vo1, 0);
+    float c = bload(F.rs, vo, sp);
+    float d = bload(F.rs, vo1, sp);
+    float e = bload(F.rs, vo, sq);
+    float f = bload(F.rs, vo1, sq);
+    float g = bload(F.rs, vo, sq + sp);
+    float h = bload(F.rs, vo1, sq + sp);
+    return trilerp8(a, b, c, d, e, f, g, h, ax.f, ay.f, az.f);
+}
+
+// The velocity field as the kernels receive it (pointers pre-offset for global z).
+struct Vel {
+    const float* __restrict__ ux;
+    const float* __restrict__ uy;
+    const float* __restrict__ uz;
+    int nx, ny, nz;
+    int pitch, plane;
+    ZRange zc;   // z limits for cell-centred-in-z arrays (ux, uy: dz = nz)
+    ZRange zf;   // z limits for uz (dz = nz + 1)
+};
+
+// ---- samplers: "velocity at a point" = the three staggered gathers of one RK stage
+// (Solver.cu:142-144) --------------------------------------------------------------------
+
+struct GlobalSampler {
+    Fld ux, uy, uz;
+    int nx, ny, pitch, plane;
+    ZRange zc, zf;
+
+    __device__ __forceinline__ void init(const Vel& v)
+    {
+        ux = make_fld(v.ux, v.zc, v.pitch, v.plane);
+        uy = make_fld(v.uy, v.zc, v.pitch, v.plane);
+        uz = make_fld(v.uz, v.zf, v.pitch, v.plane);
+        nx = v.nx; ny = v.ny; pitch = v.pitch; plane = v.plane;
+        zc = v.zc; zf = v.zf;
+    }
+    template <bool HALO>
+    __device__ __forceinline__ float3 vel(float3 p, int& bad) const
+    {
+        Axis x0 = split_axis(p.x - 0.f), xh = split_axis(p.x - 0.5f);
+        Axis y0 = split_axis(p.y - 0.f), yh = split_axis(p.y - 0.5f);
+        Axis z0 = split_axis(p.z - 0.f), zh = split_axis(p.z - 0.5f);
+        if (HALO)
+            bad |= (zh.i < zc.chk_lo) | (zh.i > zc.chk_hi) | (z0.i < zf.chk_lo) | (z0.i > zf.chk_hi);
+        float3 u;
+        u.x = gather_global(ux, x0, yh, zh, nx + 1, ny, zc, pitch, plane);
+        u.y = gather_global(uy, xh, y0, zh, nx, ny + 1, zc, pitch, plane);
+        u.z = gather_global(uz, xh, yh, z0, nx, ny, zf, pitch, plane);
+        return u;
+    }
+};
+
+// LDS brick of the three velocity arrays around an output brick of BX x BY x BZ cells.
+// All three arrays use the same index box [org, org + L) per axis; cell (x,y,z) of an array
+// sits at lds[(x-org.x) + (y-org.y)*LX + (z-org.z)*LX*LY].  The image is the zero-extended
+// array: entries outside the array's own extent are 0, like the reference's sample outside.
+template <int BX, int BY, int BZ, int H>
+struct BrickDims {
+    static constexpr int LX = BX + 2 * H + 1, LY = BY + 2 * H + 1, LZ = BZ + 2 * H + 1;
+    static constexpr int LXY = LX * LY, N = LX * LY * LZ;
+};
+
+template <class D>
+struct BrickSampler {
+    GlobalSampler G;
+    const float* lds;    // 3 * D::N floats: ux, uy, uz
+    int ox, oy, oz;      // global index of LDS element 0 along each axis
+
+    __device__ __forceinline__ float gather(int which, const Fld& F, Axis ax, Axis ay, Axis az,
+                                            int dx, int dy, const ZRange& zr) const
+    {
+        int lx = ax.i - ox, ly = ay.i - oy, lz = az.i - oz;
+        bool in = ((unsigned)lx <= (unsigned)(D::LX - 2)) & ((unsigned)ly <= (unsigned)(D::LY - 2)) &
+                  ((unsigned)lz <= (unsigned)(D::LZ - 2));
+        if (__builtin_expect(in, 1)) {
+            const float* q = lds + which * D::N + lx + ly * D::LX + lz * D::LXY;
+            float a = q[0], b = q[1], c = q[D::LX], d = q[D::LX + 1];
+            const float* q2 = q + D::LXY;
+            float e = q2[0], f = q2[1], g = q2[D::LX], h = q2[D::LX + 1];
+            return trilerp8(a, b, c, d, e, f, g, h, ax.f, ay.f, az.f);
+        }
+        return gather_global(F, ax, ay, az, dx, dy, zr, G.pitch, G.plane);
+    }
+    template <bool HALO>
+    __device__ __forceinline__ float3 vel(float3 p, int& bad) const
+    {
+        Axis x0 = split_axis(p.x - 0.f), xh = split_axis(p.x - 0.5f);
+        Axis y0 = split_axis(p.y - 0.f), yh = split_axis(p.y - 0.5f);
+        Axis z0 = split_axis(p.z - 0.f), zh = split_axis(p.z - 0.5f);
+        if (HALO)
+            bad |= (zh.i < G.zc.chk_lo) | (zh.i > G.zc.chk_hi) | (z0.i < G.zf.chk_lo) |
+                   (z0.i > G.zf.chk_hi);
+        float3 u;
+        u.x = gather(0, G.ux, x0, yh, zh, G.nx + 1, G.ny, G.zc);
+        u.y = gather(1, G.uy, xh, y0, zh, G.nx, G.ny + 1, G.zc);
+        u.z = gather(2, G.uz, xh, yh, z0, G.nx, G.ny, G.zf);
+        return u;
+    }
+};
+
+// Cooperative fill of the LDS brick: one array, zero outside its data box.
+template <class D, int THREADS>
+__device__ __forceinline__ void stage_array(float* dst, const float* __restrict__ src, int ox, int oy,
+                                            int oz, int dx, int dy, int zd_lo, int zd_hi, int pitch,
+                                            int plane)
+{
+    // Raw buffer over the array's data box: an element outside the box gets an offset past
+    // the end of the buffer, for which the hardware returns 0.  All loads of a batch are
+    // issued before the first LDS write, so their latencies overlap.
+    const float* base = src + (long)zd_lo * plane;
+    const unsigned bytes = zd_hi > zd_lo ? (unsigned)(zd_hi - zd_lo) * (unsigned)plane * 4u : 0u;
+    __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+    constexpr int PER = (D::N + THREADS - 1) / THREADS;
+    constexpr int BATCH = 8;
+#pragma unroll 1
+    for (int u0 = 0; u0 < PER; u0 += BATCH) {
+        float vals[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            int e = threadIdx.x + (u0 + u) * THREADS;
+            int lz = e / D::LXY;
+            int r = e - lz * D::LXY;
+            int ly = r / D::LX;
+            int lx = r - ly * D::LX;
+            int x = ox + lx, y = oy + ly, z = oz + lz;
+            bool ok = ((unsigned)x < (unsigned)dx) & ((unsigned)y < (unsigned)dy) & (z >= zd_lo) &
+                      (z < zd_hi) & (e < D::N);
+            unsigned off = (unsigned)(x + y * pitch + (z - zd_lo) * plane) * 4u;
+            vals[u] = bload(rs, ok ? off : 0xfffffffcu, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            int e = threadIdx.x + (u0 + u) * THREADS;
+            if (e < D::N) dst[e] = vals[u];
+        }
+    }
+}
+
+template <class D, int THREADS>
+__device__ __forceinline__ void stage_velocity(float* lds, const Vel& v, int ox, int oy, int oz)
+{
+    // data boxes: planes that hold this rank's copy of each array (ghost planes included)
+    int zc_lo = max(v.zc.lo, 0), zc_hi = min(v.zc.hi + 2, v.nz);
+    int zf_lo = max(v.zf.lo, 0), zf_hi = min(v.zf.hi + 2, v.nz + 1);
+    stage_array<D, THREADS>(lds, v.ux, ox, oy, oz, v.nx + 1, v.ny, zc_lo, zc_hi, v.pitch, v.plane);
+    stage_array<D, THREADS>(lds + D::N, v.uy, ox, oy, oz, v.nx, v.ny + 1, zc_lo, zc_hi, v.pitch, v.plane);
+    stage_array<D, THREADS>(lds + 2 * D::N, v.uz, ox, oy, oz, v.nx, v.ny, zf_lo, zf_hi, v.pitch, v.plane);
+}
+
+// ---- back-trace ----------------------------------------------------------------------------
+
+// Solver.cu:139-161.  (0.5f*dt) is formed first, then scales each component
+// (Math.cuh:80-86); the final update is  pos - (dt * sum) / 6  with a true division.
+template <bool HALO, class S>
+__device__ __forceinline__ float3 rk4(const S& s, float3 pos, float dt, int& bad)
+{
+    float hdt = 0.5f * dt;
+    float3 u1 = s.template vel<HALO>(pos, bad);
+    float3 p1 = make_float3(pos.x - hdt * u1.x, pos.y - hdt * u1.y, pos.z - hdt * u1.z);
+    float3 u2 = s.template vel<HALO>(p1, bad);
+    float3 p2 = make_float3(pos.x - hdt * u2.x, pos.y - hdt * u2.y, pos.z - hdt * u2.z);
+    float3 u3 = s.template vel<HALO>(p2, bad);
+    float3 p3 = make_float3(pos.x - dt * u3.x, pos.y - dt * u3.y, pos.z - dt * u3.z);
+    float3 u4 = s.template vel<HALO>(p3, bad);
+    float sx = ((u1.x + 2.0f * u2.x) + 2.0f * u3.x) + u4.x;
+    float sy = ((u1.y + 2.0f * u2.y) + 2.0f * u3.y) + u4.y;
+    float sz = ((u1.z + 2.0f * u2.z) + 2.0f * u3.z) + u4.z;
+    return make_float3(pos.x - (dt * sx) / 6.0f, pos.y - (dt * sy) / 6.0f,
+                       pos.z - (dt * sz) / 6.0f);
+}
+
+// Solver.cu:163-169 (MAC) or the plain RK4 trace of Solver.cu:396.
+template <bool MAC, bool HALO, class S>
+__device__ __forceinline__ float3 backtrace(const S& s, float3 pos, float dt, int& bad)
+{
+    float3 pred = rk4<HALO>(s, pos, dt, bad);
+    if (!MAC) return pred;
+    float3 refl = rk4<HALO>(s, pred, -dt, bad);
+    return make_float3(pred.x + (pos.x - refl.x) / 2.f, pred.y + (pos.y - refl.y) / 2.f,
+                       pred.z + (pos.z - refl.z) / 2.f);
+}
+
+// One advected velocity component at face (i,j,k): Solver.cu:377-400 for dir = DIR.
+template <int DIR, bool MAC, bool HALO, class S>
+__device__ __forceinline__ float advect_component(const S& s, const GlobalSampler& G, int i, int j,
+                                                  int k, float dt, int& bad)
+{
+    float3 pos;   // Solver.cu:381-383
+    pos.x = (float)i + (DIR == 1 ? 0.f : 0.5f);
+    pos.y = (float)j + (DIR == 2 ? 0.f : 0.5f);
+    pos.z = (float)k + (DIR == 3 ? 0.f : 0.5f);
+    float3 c = backtrace<MAC, HALO>(s, pos, dt, bad);
+    Axis ax = split_axis(c.x - (DIR == 1 ? 0.f : 0.5f));
+    Axis ay = split_axis(c.y - (DIR == 2 ? 0.f : 0.5f));
+    Axis az = split_axis(c.z - (DIR == 3 ? 0.f : 0.5f));
+    const ZRange& zr = DIR == 3 ? G.zf : G.zc;
+    if (HALO) bad |= (az.i < zr.chk_lo) | (az.i > zr.chk_hi);
+    // the advected field is the component itself (Solver.cu:1153-1155)
+    return gather_global(DIR == 1 ? G.ux : (DIR == 2 ? G.uy : G.uz), ax, ay, az,
+                         DIR == 1 ? G.nx + 1 : G.nx, DIR == 2 ? G.ny + 1 : G.ny, zr, G.pitch,
+                         G.plane);
+}
+
+__host__ inline ZRange make_zrange(const FsGrid& g, int dz)
+{
+    ZRange r;
+    r.lo = g.wall_lo ? -2 : g.z0 - g.ghost;
+    r.hi = g.wall_hi ? dz : g.z0 + g.nzl + g.ghost - 1;
+    r.chk_lo = g.wall_lo ? INT_MIN : r.lo;
+    r.chk_hi = g.wall_hi ? INT_MAX : r.hi;
+    return r;
+}
+
+__host__ inline Vel make_vel(const FsGrid& g, const float* ux, const float* uy, const float* uz)
+{
+    Vel v;
+    ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
+    v.ux = ux - zoff;
+    v.uy = uy - zoff;
+    v.uz = uz - zoff;
+    v.nx = g.nx;
+    v.ny = g.ny;
+    v.nz = g.nz;
+    v.pitch = g.pitch;
+    v.plane = g.plane;
+    v.zc = make_zrange(g, g.nz);
+    v.zf = make_zrange(g, g.nz + 1);
+    return v;
+}
+
+// ---------------------------------------------------------------- brick mapping
+
+// Workgroups are dealt round-robin to the 8 XCDs, so ids b and b+8 share an L2.  Give each
+// XCD one contiguous run of bricks (bijective for any count).
+__device__ __forceinline__ int xcd_contiguous(int b, int nb)
+{
+    int q = nb >> 3, r = nb & 7;
+    int xcd = b & 7, loc = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// The box of cells one launch covers and its decomposition into bricks.
+struct Box {
+    int x0, y0, z0;      // first cell (global indices)
+    int nx, ny, nz;      // extent in cells
+    int bx, by;          // bricks along x and y
+    int nb;              // total bricks
+};
+
+__host__ inline Box make_box(int tx, int ty, int tz, int x0, int y0, int z0, int nx, int ny, int nz)
+{
+    Box b;
+    b.x0 = x0; b.y0 = y0; b.z0 = z0;
+    b.nx = nx; b.ny = ny; b.nz = nz;
+    b.bx = cdiv(nx, tx);
+    b.by = cdiv(ny, ty);
+    b.nb = b.bx * b.by * cdiv(nz, tz);
+    return b;
+}
+
+// brick coordinates (in bricks) of this workgroup
+__device__ __forceinline__ void brick_of_block(const Box& B, int& bx, int& by, int& bz)
+{
+    int id = xcd_contiguous((int)blockIdx.x, B.nb);
+    bz = id / (B.bx * B.by);
+    int rem = id - bz * (B.bx * B.by);
+    by = rem / B.bx;
+    bx = rem - by * B.bx;
+}
+
+// ---------------------------------------------------------------- kernels
+
+// Brick shape of the LDS kernels: 32 x 8 x 4 cells, halo 3, 512 threads (two cells each).
+constexpr int kBX = 32, kBY = 8, kBZ = 4, kHalo = 3, kThreads = 512;
+using Dims = BrickDims<kBX, kBY, kBZ, kHalo>;
+
+// ux, uy, uz advected from the old velocity, all faces with i < B.x0 + B.nx.  Cell (i,j,k) of
+// the box owns face i of ux (if j < ny, k < zend), face j of uy (if k < zend) and face k of uz
+// (if j < ny); the box spans j in [0, ny] and k in [z0, zend].
+template <bool MAC, bool HALO>
+__global__ void __launch_bounds__(kThreads)
+k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* __restrict__ nuz, Vel v,
+                      float dt, Box B, int zend, int* halo_flag)
+{
+    __shared__ float lds[3 * Dims::N];
+    int bx, by, bz;
+    brick_of_block(B, bx, by, bz);
+    const int X0 = B.x0 + bx * kBX, Y0 = B.y0 + by * kBY, Z0 = B.z0 + bz * kBZ;
+    BrickSampler<Dims> S;
+    S.G.init(v);
+    S.lds = lds;
+    S.ox = X0 - kHalo;
+    S.oy = Y0 - kHalo;
+    S.oz = Z0 - kHalo;
+    stage_velocity<Dims, kThreads>(lds, v, S.ox, S.oy, S.oz);
+    __syncthreads();
+
+    const int t = threadIdx.x;
+    const int lx = t % kBX, ly = (t / kBX) % kBY, lz0 = t / (kBX * kBY);
+    int bad = 0;
+#pragma unroll 1
+    for (int lz = lz0; lz < kBZ; lz += kThreads / (kBX * kBY)) {
+        const int i = X0 + lx, j = Y0 + ly, k = Z0 + lz;
+        if (i >= B.x0 + B.nx || j >= B.y0 + B.ny || k >= B.z0 + B.nz) continue;
+        const int o = i + j * v.pitch + k * v.plane;
+        if (j < v.ny && k < zend) nux[o] = advect_component<1, MAC, HALO>(S, S.G, i, j, k, dt, bad);
+        if (k < zend) nuy[o] = advect_component<2, MAC, HALO>(S, S.G, i, j, k, dt, bad);
+        if (j < v.ny) nuz[o] = advect_component<3, MAC, HALO>(S, S.G, i, j, k, dt, bad);
+    }
+    if (HALO && bad) atomicOr(halo_flag, 1);
+}
+
+// T and rho advected with the new velocity; they share one back-trace (same sample position,
+// Solver.cu:381-383 with dir = 0, and same velocity, Solver.cu:1160-1164).
+template <bool MAC, bool HALO>
+__global__ void __launch_bounds__(kThreads)
+k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const float* __restrict__ rho,
+                     float* __restrict__ nrho, Vel v, float dt, Box B, int* halo_flag)
+{
+    __shared__ float lds[3 * Dims::N];
+    int bx, by, bz;
+    brick_of_block(B, bx, by, bz);
+    const int X0 = B.x0 + bx * kBX, Y0 = B.y0 + by * kBY, Z0 = B.z0 + bz * kBZ;
+    BrickSampler<Dims> S;
+    S.G.init(v);
+    S.lds = lds;
+    S.ox = X0 - kHalo;
+    S.oy = Y0 - kHalo;
+    S.oz = Z0 - kHalo;
+    stage_velocity<Dims, kThreads>(lds, v, S.ox, S.oy, S.oz);
+    __syncthreads();
+    const Fld FT = make_fld(T, v.zc, v.pitch, v.plane), FR = make_fld(rho, v.zc, v.pitch, v.plane);
+
+    const int t = threadIdx.x;
+    const int lx = t % kBX, ly = (t / kBX) % kBY, lz0 = t / (kBX * kBY);
+    int bad = 0;
+#pragma unroll 1
+    for (int lz = lz0; lz < kBZ; lz += kThreads / (kBX * kBY)) {
+        const int i = X0 + lx, j = Y0 + ly, k = Z0 + lz;
+        if (i >= B.x0 + B.nx || j >= B.y0 + B.ny || k >= B.z0 + B.nz) continue;
+        float3 pos = make_float3((float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f);
+        float3 c = backtrace<MAC, HALO>(S, pos, dt, bad);
+        Axis ax = split_axis(c.x - 0.5f), ay = split_axis(c.y - 0.5f), az = split_axis(c.z - 0.5f);
+        if (HALO) bad |= (az.i < v.zc.chk_lo) | (az.i > v.zc.chk_hi);
+        const int o = i + j * v.pitch + k * v.plane;
+        nT[o] = gather_global(FT, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+        nrho[o] = gather_global(FR, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+    }
+    if (HALO && bad) atomicOr(halo_flag, 1);
+}
+
+// Global-path kernel for one velocity component over an arbitrary box of faces (used for the
+// faces the brick kernel does not cover, and for A/B timing): TX x TY x TZ threads, one face each.
+template <int DIR, bool MAC, bool HALO, int TX, int TY, int TZ>
+__global__ void __launch_bounds__(TX * TY * TZ)
+k_advect_component_global(float* __restrict__ out, Vel v, float dt, Box B, int* halo_flag)
+{
+    int bx, by, bz;
+    brick_of_block(B, bx, by, bz);
+    const int t = threadIdx.x;
+    const int x = bx * TX + t % TX, y = by * TY + (t / TX) % TY, z = bz * TZ + t / (TX * TY);
+    if (x >= B.nx || y >= B.ny || z >= B.nz) return;
+    const int i = B.x0 + x, j = B.y0 + y, k = B.z0 + z;
+    GlobalSampler G;
+    G.init(v);
+    int bad = 0;
+    out[i + j * v.pitch + k * v.plane] = advect_component<DIR, MAC, HALO>(G, G, i, j, k, dt, bad);
+    if (HALO && bad) atomicOr(halo_flag, 1);
+}
+
+template <bool MAC, bool HALO, int TX, int TY, int TZ>
+__global__ void __launch_bounds__(TX * TY * TZ)
+k_advect_scalars_global(const float* __restrict__ T, float* __restrict__ nT,
+                        const float* __restrict__ rho, float* __restrict__ nrho, Vel v, float dt, Box B,
+                        int* halo_flag)
+{
+    int bx, by, bz;
+    brick_of_block(B, bx, by, bz);
+    const int t = threadIdx.x;
+    const int x = bx * TX + t % TX, y = by * TY + (t / TX) % TY, z = bz * TZ + t / (TX * TY);
+    if (x >= B.nx || y >= B.ny || z >= B.nz) return;
+    const int i = B.x0 + x, j = B.y0 + y, k = B.z0 + z;
+    GlobalSampler G;
+    G.init(v);
+    const Fld FT = make_fld(T, v.zc, v.pitch, v.plane), FR = make_fld(rho, v.zc, v.pitch, v.plane);
+    int bad = 0;
+    float3 pos = make_float3((float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f);
+    float3 c = backtrace<MAC, HALO>(G, pos, dt, bad);
+    Axis ax = split_axis(c.x - 0.5f), ay = split_axis(c.y - 0.5f), az = split_axis(c.z - 0.5f);
+    if (HALO) bad |= (az.i < v.zc.chk_lo) | (az.i > v.zc.chk_hi);
+    const int o = i + j * v.pitch + k * v.plane;
+    nT[o] = gather_global(FT, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+    nrho[o] = gather_global(FR, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+    if (HALO && bad) atomicOr(halo_flag, 1);
+}
+
+// FS_ADVECT_GLOBAL (timing experiments): bit 0 = velocity on the global path, bit 1 = scalars
+// on the LDS-brick path.  Default: velocity through LDS bricks (three back-traces share one
+// staged brick), scalars on the global path (one back-trace does not repay the staging).
+int path_mask()
+{
+    static int v = [] {
+        const char* e = getenv("FS_ADVECT_GLOBAL");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+bool use_global_path() { return (path_mask() & 1) != 0; }
+bool scalars_use_lds() { return (path_mask() & 2) != 0; }
+
+#define FS_DISPATCH_MH(mac, halo, CALL)   \
+    do {                                  \
+        if (mac && halo) CALL(true, true);    \
+        else if (mac) CALL(true, false);      \
+        else if (halo) CALL(false, true);     \
+        else CALL(false, false);              \
+    } while (0)
+
+template <int DIR>
+void launch_component_global(hipStream_t st, float* out, const Vel& v, float dt, bool mac, bool halo,
+                             int x0, int y0, int z0, int nx, int ny, int nz, bool thin_x,
+                             int* halo_flag)
+{
+    if (nx <= 0 || ny <= 0 || nz <= 0) return;
+    if (thin_x) {
+        Box B = make_box(1, 64, 4, x0, y0, z0, nx, ny, nz);
+#define FS_CALL(M, H)                                                                          \
+    hipLaunchKernelGGL((k_advect_component_global<DIR, M, H, 1, 64, 4>), dim3(B.nb), dim3(256), 0, st, \
+                       out, v, dt, B, halo_flag)
+        FS_DISPATCH_MH(mac, halo, FS_CALL);
+#undef FS_CALL
+    } else {
+        Box B = make_box(64, 4, 1, x0, y0, z0, nx, ny, nz);
+#define FS_CALL(M, H)                                                                          \
+    hipLaunchKernelGGL((k_advect_component_global<DIR, M, H, 64, 4, 1>), dim3(B.nb), dim3(256), 0, st, \
+                       out, v, dt, B, halo_flag)
+        FS_DISPATCH_MH(mac, halo, FS_CALL);
+#undef FS_CALL
+    }
+}
+
+}  // namespace
+
+namespace fsk {
+
+int advect_velocity_launches(const FsGrid& g) { (void)g; return use_global_path() ? 3 : 2; }
+
+void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, float* nuz,
+                     const float* ux, const float* uy, const float* uz, float dt, int scheme,
+                     int* halo_flag)
+{
+    Vel v = make_vel(g, ux, uy, uz);
+    const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0;
+    const ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
+    float *ox = nux - zoff, *oy = nuy - zoff, *oz = nuz - zoff;
+    const int zend = g.z0 + g.nzl;
+    if (use_global_path()) {
+        launch_component_global<1>(st, ox, v, dt, mac, halo, 0, 0, g.z0, g.nx + 1, g.ny, g.nzl, false, halo_flag);
+        launch_component_global<2>(st, oy, v, dt, mac, halo, 0, 0, g.z0, g.nx, g.ny + 1, g.nzl, false, halo_flag);
+        launch_component_global<3>(st, oz, v, dt, mac, halo, 0, 0, g.z0, g.nx, g.ny, g.nzl + 1, false, halo_flag);
+        return;
+    }
+    // brick kernel: all faces with i < nx; the ux faces at i = nx go through the global path
+    Box B = make_box(kBX, kBY, kBZ, 0, 0, g.z0, g.nx, g.ny + 1, g.nzl + 1);
+#define FS_CALL(M, H)                                                                              \
+    hipLaunchKernelGGL((k_advect_velocity_lds<M, H>), dim3(B.nb), dim3(kThreads), 0, st, ox, oy, oz, v, \
+                       dt, B, zend, halo_flag)
+    FS_DISPATCH_MH(mac, halo, FS_CALL);
+#undef FS_CALL
+    launch_component_global<1>(st, ox, v, dt, mac, halo, g.nx, 0, g.z0, 1, g.ny, g.nzl, true, halo_flag);
+}
+
+void advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
+                    float* nrho, const float* ux, const float* uy, const float* uz, float dt,
+                    int scheme, int* halo_flag)
+{
+    Vel v = make_vel(g, ux, uy, uz);
+    const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0;
+    const ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
+    if (!scalars_use_lds()) {
+        Box B = make_box(64, 4, 1, 0, 0, g.z0, g.nx, g.ny, g.nzl);
+#define FS_CALL(M, H)                                                                             \
+    hipLaunchKernelGGL((k_advect_scalars_global<M, H, 64, 4, 1>), dim3(B.nb), dim3(256), 0, st,   \
+                       T - zoff, nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag)
+        FS_DISPATCH_MH(mac, halo, FS_CALL);
+#undef FS_CALL
+        return;
+    }
+    Box B = make_box(kBX, kBY, kBZ, 0, 0, g.z0, g.nx, g.ny, g.nzl);
+#define FS_CALL(M, H)                                                                             \
+    hipLaunchKernelGGL((k_advect_scalars_lds<M, H>), dim3(B.nb), dim3(kThreads), 0, st, T - zoff, \
+                       nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag)
+    FS_DISPATCH_MH(mac, halo, FS_CALL);
+#undef FS_CALL
+}
+
+}  // namespace fsk

@@ -288,8 +288,8 @@ int tb_config()
 {
     static int cfg = [] {
         const char* e = getenv("FS_JACOBI_CFG");
-        int v = e ? atoi(e) : 0;
-        return (v >= 0 && v < kNumConfigs) ? v : 0;
+        int v = e ? atoi(e) : 2;
+        return (v >= 0 && v < kNumConfigs) ? v : 2;
     }();
     return cfg;
 }

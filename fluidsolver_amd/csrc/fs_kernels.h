@@ -38,10 +38,11 @@ namespace fsk {
 void fill_interior(hipStream_t st, const FsGrid& g, float* f, float value);
 void source(hipStream_t st, const FsGrid& g, const FsSource& src, float* rho, float* T);
 void force_uy(hipStream_t st, const FsGrid& g, float* uy, const float* T, float dt, float T_env);
-// dir 1,2,3: advect one velocity component from the old velocity (ux,uy,uz) into out.
-void advect_velocity(hipStream_t st, const FsGrid& g, int dir, const float* field, float* out,
+// Advect all three velocity components from the old velocity (ux,uy,uz) into (nux,nuy,nuz).
+void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, float* nuz,
                      const float* ux, const float* uy, const float* uz, float dt, int scheme,
                      int* halo_flag);
+int advect_velocity_launches(const FsGrid& g);
 // T and rho share one back-trace (same sample position, Solver.cu:381-383 with dir = 0).
 void advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
                     float* nrho, const float* ux, const float* uy, const float* uz, float dt,

@@ -345,10 +345,8 @@ int fs_stage_advect(fs_solver* s)
     const int sc = s->prm.scheme;
     // Solver.cu:1153-1158: all three components from the OLD velocity, then swap
     {
-        StageScope ps(s, FS_STAGE_ADVECT_VELOCITY, 3);
-        fsk::advect_velocity(s->st, s->g, 1, f.ux, f.nux, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
-        fsk::advect_velocity(s->st, s->g, 2, f.uy, f.nuy, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
-        fsk::advect_velocity(s->st, s->g, 3, f.uz, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+        StageScope ps(s, FS_STAGE_ADVECT_VELOCITY, fsk::advect_velocity_launches(s->g));
+        fsk::advect_velocity(s->st, s->g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
     }
     std::swap(f.ux, f.nux);
     std::swap(f.uy, f.nuy);
