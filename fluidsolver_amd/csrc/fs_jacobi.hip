@@ -357,6 +357,22 @@ void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, co
                        g.nz, g.pitch, g.plane, zb);
 }
 
+int jacobi_block() { return kT; }
+
+bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
+                 int sweeps, int zin_lo, int zin_hi, int zout_lo, int zout_hi)
+{
+    if (!can_block(g) || sweeps < 1 || sweeps > kT) return false;
+    if (zout_hi <= zout_lo) return true;
+    switch (sweeps) {
+    case 1: launch_tb<1>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi); break;
+    case 2: launch_tb<2>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi); break;
+    case 3: launch_tb<3>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi); break;
+    default: launch_tb<4>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi); break;
+    }
+    return true;
+}
+
 int jacobi_launches(const FsGrid& g, int sweeps, int naive)
 {
     if (naive || !can_block(g)) return sweeps;

@@ -47,8 +47,9 @@ int advect_velocity_launches(const FsGrid& g);
 void advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
                     float* nrho, const float* ux, const float* uy, const float* uz, float dt,
                     int scheme, int* halo_flag);
+// cell planes [zb, ze) (global indices); the faces uz[ze] must be held locally
 void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, const float* uy,
-                const float* uz);
+                const float* uz, int zb, int ze);
 // one Jacobi sweep p -> np over the owned planes [zb, ze) (global indices)
 void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
                   int zb, int ze);
@@ -58,6 +59,13 @@ void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, co
 // Single-slab (no halo exchange) only.
 void jacobi_multi(hipStream_t st, const FsGrid& g, float* p, float* np, const float* div,
                   int sweeps, int naive, int* result_in_np, int* prev_held);
+// One pass of `sweeps` (1..jacobi_block()) fused sweeps p -> np: level-0 planes [zin_lo, zin_hi)
+// are read (ghost planes included), planes [zout_lo, zout_hi) are written.  A plane range edge
+// that is not a global wall loses one plane of validity per sweep, so zout must lie `sweeps`
+// planes inside zin there.  Returns false if this grid cannot take the fused kernel.
+bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
+                 int sweeps, int zin_lo, int zin_hi, int zout_lo, int zout_hi);
+int jacobi_block();   // sweeps fused per pass
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
 int jacobi_launches(const FsGrid& g, int sweeps, int naive);
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p);

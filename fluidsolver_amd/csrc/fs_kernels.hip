@@ -204,10 +204,13 @@ void force_uy(hipStream_t st, const FsGrid& g, float* uy, const float* T, float 
 }
 
 void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, const float* uy,
-                const float* uz)
+                const float* uz, int zb, int ze)
 {
-    hipLaunchKernelGGL(k_divergence, tile_grid(g.nx, g.ny, g.nzl), kTile, 0, st, div, ux, uy, uz,
-                       g.nx, g.ny, g.pitch, g.plane);
+    if (ze <= zb) return;
+    // planes [zb, ze) in global indices; local plane 0 is global z0
+    ptrdiff_t o = (ptrdiff_t)(zb - g.z0) * g.plane;
+    hipLaunchKernelGGL(k_divergence, tile_grid(g.nx, g.ny, ze - zb), kTile, 0, st, div + o, ux + o,
+                       uy + o, uz + o, g.nx, g.ny, g.pitch, g.plane);
 }
 
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p)

@@ -4,8 +4,22 @@
 // stage order (reference: CuSolver/Source/Solver.cu:1009-1114 UpdateCuda, 1145-1165
 // Advect, 1168-1189 Project on its Jacobi branch), ping-pong swaps (Solver.cu:181-186),
 // host getters (Solver.cu:1368-1372).
+//
+// Multi-GPU: the grid is cut into z-slabs, one per rank (one process per GPU).  A rank owns
+// cell planes [z0, z1) and the uz face planes [z0, z1]; face plane z1 is computed by both
+// neighbours from identical inputs, so results are bit-identical to one GPU.  Every array
+// carries `ghost` planes on each z side.  Ghost planes are refreshed lazily, only when a stage
+// needs them: old velocity + T + rho before the velocity advection, the new velocity before the
+// scalar advection, jacobi_block() planes of p before each fused Jacobi pass (one exchange per
+// 4 sweeps), one plane of p before the gradient.  Planes are contiguous in memory, so a halo is
+// one send and one receive per field and neighbour, straight from and into the arrays, with
+// RCCL (ncclSend/ncclRecv in one group, on a communication stream ordered against the compute
+// stream by events).  The only collective is the all-reduce of the residual norm.
 #include "../../include/fluidsolver.h"
 #include "fs_kernels.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -41,6 +55,66 @@ int fail(int code, const char* fmt, ...)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// ---- RCCL, loaded on first use so that single-GPU users never touch it -------------------
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return nullptr;
+#define FS_SYM(field, name)                                                   \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name));        \
+    if (!r.field) {                                                           \
+        r.lib = nullptr;                                                      \
+        return nullptr;                                                       \
+    }
+    FS_SYM(GetUniqueId, "ncclGetUniqueId")
+    FS_SYM(CommInitRank, "ncclCommInitRank")
+    FS_SYM(CommDestroy, "ncclCommDestroy")
+    FS_SYM(Send, "ncclSend")
+    FS_SYM(Recv, "ncclRecv")
+    FS_SYM(GroupStart, "ncclGroupStart")
+    FS_SYM(GroupEnd, "ncclGroupEnd")
+    FS_SYM(AllReduce, "ncclAllReduce")
+    FS_SYM(GetErrorString, "ncclGetErrorString")
+#undef FS_SYM
+    return &r;
+}
+
+#define FS_NCCL(call)                                                                          \
+    do {                                                                                       \
+        ncclResult_t e_ = (call);                                                              \
+        if (e_ != ncclSuccess)                                                                 \
+            return fail(FS_ERR_COMM, "%s failed: %s (%s:%d)", #call, rccl()->GetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// one halo segment: contiguous planes sent to / received from the lower and upper neighbour
+struct Seg {
+    float *send_lo, *recv_lo, *send_hi, *recv_hi;
+    size_t n;   // floats per direction
+};
+
 }  // namespace
 
 struct fs_solver {
@@ -48,7 +122,7 @@ struct fs_solver {
     FsGrid g{};
     FsFields f{};
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;         // compute stream
     float* pool = nullptr;            // one allocation holding all 13 fields
     size_t field_elems = 0;           // floats per field including slack and ghost planes
     size_t origin = 0;                // offset of element (0,0,z0) inside a field
@@ -61,6 +135,17 @@ struct fs_solver {
     int frame = 0;
     int last_sweeps = 0;
     bool prev_held = false;           // np holds the iterate before the last sweep
+    // slab decomposition
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    fs_exchange_fn xfn = nullptr;     // host-staged transport (tests, fallback)
+    void* xctx = nullptr;
+    hipStream_t cs = nullptr;         // communication stream
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    char* h_stage[4] = {};            // pinned: send_lo, recv_lo, send_hi, recv_hi
+    size_t h_stage_cap = 0;
+    bool vel_ghost_ok = false, scal_ghost_ok = false;
+    int p_ghost = 0;                  // valid ghost planes of p on each side
     // stage timing with HIP events on the solver's own stream (fs_profile_*)
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
@@ -72,11 +157,12 @@ struct fs_solver {
 
 namespace {
 
+// dims of the LOCAL part of a field (what the host getters return)
 void field_dims(const fs_solver* s, int field, int& dx, int& dy, int& dz)
 {
     dx = s->g.nx + (field == FS_UX);
     dy = s->g.ny + (field == FS_UY);
-    dz = s->g.nz + (field == FS_UZ);
+    dz = s->g.nzl + (field == FS_UZ);
 }
 
 float** field_slot(fs_solver* s, int field)
@@ -127,94 +213,210 @@ int check_flag(fs_solver* s)
     FS_HIP(hipMemcpyAsync(s->h_flag, s->d_flag, sizeof(int), hipMemcpyDeviceToHost, s->st));
     FS_HIP(hipStreamSynchronize(s->st));
     if (*s->h_flag)
-        return fail(FS_ERR_HALO, "a back-trace left the %d ghost planes of the z-slab", s->g.ghost);
+        return fail(FS_ERR_HALO, "rank %d: a back-trace left the %d ghost planes of the z-slab",
+                    s->rank, s->g.ghost);
     return FS_OK;
 }
+
+// ---- halo exchange -------------------------------------------------------------------------
+
+// Segment for `n` ghost planes of one array.  base addresses local plane 0.  Cell-type arrays
+// own planes [0, nzl); the face array uz owns [0, nzl] and shares plane nzl with the upper
+// neighbour (its plane 0), so its exchanged ranges are shifted by one plane.
+Seg make_seg(const fs_solver* s, float* base, int n, bool face)
+{
+    const size_t pl = (size_t)s->g.plane;
+    const int nzl = s->g.nzl, f = face ? 1 : 0;
+    Seg g;
+    g.n = (size_t)n * pl;
+    g.send_lo = s->g.wall_lo ? nullptr : base + (size_t)f * pl;
+    g.recv_lo = s->g.wall_lo ? nullptr : base - (ptrdiff_t)n * (ptrdiff_t)pl;
+    g.send_hi = s->g.wall_hi ? nullptr : base + (size_t)(nzl - n) * pl;
+    g.recv_hi = s->g.wall_hi ? nullptr : base + (size_t)(nzl + f) * pl;
+    return g;
+}
+
+int exchange(fs_solver* s, const Seg* segs, int nseg)
+{
+    if (s->world == 1 || nseg == 0) return FS_OK;
+    const bool lo = !s->g.wall_lo, hi = !s->g.wall_hi;
+    if (s->comm) {
+        Rccl* R = rccl();
+        // communication stream waits for the producers on the compute stream ...
+        FS_HIP(hipEventRecord(s->ev_ready, s->st));
+        FS_HIP(hipStreamWaitEvent(s->cs, s->ev_ready, 0));
+        FS_NCCL(R->GroupStart());
+        for (int q = 0; q < nseg; ++q) {
+            const Seg& g = segs[q];
+            if (lo) {
+                FS_NCCL(R->Send(g.send_lo, g.n, ncclFloat, s->rank - 1, s->comm, s->cs));
+                FS_NCCL(R->Recv(g.recv_lo, g.n, ncclFloat, s->rank - 1, s->comm, s->cs));
+            }
+            if (hi) {
+                FS_NCCL(R->Send(g.send_hi, g.n, ncclFloat, s->rank + 1, s->comm, s->cs));
+                FS_NCCL(R->Recv(g.recv_hi, g.n, ncclFloat, s->rank + 1, s->comm, s->cs));
+            }
+        }
+        FS_NCCL(R->GroupEnd());
+        // ... and the consumers on the compute stream wait for the halos
+        FS_HIP(hipEventRecord(s->ev_done, s->cs));
+        FS_HIP(hipStreamWaitEvent(s->st, s->ev_done, 0));
+        return FS_OK;
+    }
+    // host-staged transport: pack through pinned buffers, let the caller's function move them
+    size_t bytes = 0;
+    for (int q = 0; q < nseg; ++q) bytes += segs[q].n * sizeof(float);
+    if (bytes > s->h_stage_cap) {
+        for (char*& b : s->h_stage) {
+            if (b) (void)hipHostFree(b);
+            b = nullptr;
+            FS_HIP(hipHostMalloc((void**)&b, bytes));
+        }
+        s->h_stage_cap = bytes;
+    }
+    size_t off = 0;
+    for (int q = 0; q < nseg; ++q) {
+        const size_t nb = segs[q].n * sizeof(float);
+        if (lo) FS_HIP(hipMemcpyAsync(s->h_stage[0] + off, segs[q].send_lo, nb, hipMemcpyDeviceToHost, s->st));
+        if (hi) FS_HIP(hipMemcpyAsync(s->h_stage[2] + off, segs[q].send_hi, nb, hipMemcpyDeviceToHost, s->st));
+        off += nb;
+    }
+    FS_HIP(hipStreamSynchronize(s->st));
+    int rc = s->xfn(s->xctx, FS_XCHG_HALO, lo ? s->h_stage[0] : nullptr, lo ? s->h_stage[1] : nullptr,
+                    hi ? s->h_stage[2] : nullptr, hi ? s->h_stage[3] : nullptr, bytes);
+    if (rc) return fail(FS_ERR_COMM, "rank %d: the exchange callback returned %d", s->rank, rc);
+    off = 0;
+    for (int q = 0; q < nseg; ++q) {
+        const size_t nb = segs[q].n * sizeof(float);
+        if (lo) FS_HIP(hipMemcpyAsync(segs[q].recv_lo, s->h_stage[1] + off, nb, hipMemcpyHostToDevice, s->st));
+        if (hi) FS_HIP(hipMemcpyAsync(segs[q].recv_hi, s->h_stage[3] + off, nb, hipMemcpyHostToDevice, s->st));
+        off += nb;
+    }
+    return FS_OK;
+}
+
+int ensure_velocity_ghosts(fs_solver* s)
+{
+    if (s->world == 1 || s->vel_ghost_ok) return FS_OK;
+    Seg segs[3] = {make_seg(s, s->f.ux, s->g.ghost, false), make_seg(s, s->f.uy, s->g.ghost, false),
+                   make_seg(s, s->f.uz, s->g.ghost, true)};
+    int rc = exchange(s, segs, 3);
+    if (rc == FS_OK) s->vel_ghost_ok = true;
+    return rc;
+}
+
+int ensure_scalar_ghosts(fs_solver* s)
+{
+    if (s->world == 1 || s->scal_ghost_ok) return FS_OK;
+    Seg segs[2] = {make_seg(s, s->f.T, s->g.ghost, false), make_seg(s, s->f.rho, s->g.ghost, false)};
+    int rc = exchange(s, segs, 2);
+    if (rc == FS_OK) s->scal_ghost_ok = true;
+    return rc;
+}
+
+// old velocity, T and rho in one group (what the advection of a step starts from)
+int ensure_advect_ghosts(fs_solver* s)
+{
+    if (s->world == 1) return FS_OK;
+    Seg segs[5];
+    int n = 0;
+    if (!s->vel_ghost_ok) {
+        segs[n++] = make_seg(s, s->f.ux, s->g.ghost, false);
+        segs[n++] = make_seg(s, s->f.uy, s->g.ghost, false);
+        segs[n++] = make_seg(s, s->f.uz, s->g.ghost, true);
+    }
+    if (!s->scal_ghost_ok) {
+        segs[n++] = make_seg(s, s->f.T, s->g.ghost, false);
+        segs[n++] = make_seg(s, s->f.rho, s->g.ghost, false);
+    }
+    int rc = exchange(s, segs, n);
+    if (rc == FS_OK) s->vel_ghost_ok = s->scal_ghost_ok = true;
+    return rc;
+}
+
+int ensure_p_ghosts(fs_solver* s, int planes)
+{
+    if (s->world == 1 || s->p_ghost >= planes) return FS_OK;
+    Seg seg = make_seg(s, s->f.p, planes, false);
+    int rc = exchange(s, &seg, 1);
+    if (rc == FS_OK) s->p_ghost = planes;
+    return rc;
+}
+
+// ---- Jacobi ----------------------------------------------------------------------------------
 
 int run_jacobi(fs_solver* s, int sweeps)
 {
     if (sweeps <= 0) return FS_OK;
-    int in_np = 0;
-    {
-        int naive = (s->prm.flags & FS_FLAG_JACOBI_NAIVE) ? 1 : 0;
-        StageScope sc(s, FS_STAGE_JACOBI, fsk::jacobi_launches(s->g, sweeps, naive));
-        int held = 0;
-        fsk::jacobi_multi(s->st, s->g, s->f.p, s->f.np, s->f.div, sweeps, naive, &in_np, &held);
+    const FsGrid& g = s->g;
+    const int naive = (s->prm.flags & FS_FLAG_JACOBI_NAIVE) ? 1 : 0;
+    if (s->world == 1) {
+        int in_np = 0, held = 0;
+        {
+            StageScope sc(s, FS_STAGE_JACOBI, fsk::jacobi_launches(g, sweeps, naive));
+            fsk::jacobi_multi(s->st, g, s->f.p, s->f.np, s->f.div, sweeps, naive, &in_np, &held);
+        }
         s->prev_held = held != 0;
+        if (in_np) std::swap(s->f.p, s->f.np);
+    } else {
+        // slab: refresh t ghost planes of p, then t fused sweeps over the owned planes; a slab
+        // face that is not a global wall loses one plane of validity per sweep, which is what the
+        // t ghost planes pay for
+        const int T = naive ? 1 : fsk::jacobi_block();
+        const int z1 = g.z0 + g.nzl;
+        int left = sweeps, launches = 0;
+        StageScope sc(s, FS_STAGE_JACOBI, 0);
+        while (left > 0) {
+            int t = left < T ? left : T;
+            int rc = ensure_p_ghosts(s, t);
+            if (rc) return rc;
+            const int zin_lo = g.wall_lo ? 0 : g.z0 - t, zin_hi = g.wall_hi ? g.nz : z1 + t;
+            bool fused = !naive && fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo,
+                                                    zin_hi, g.z0, z1);
+            if (!fused) {
+                t = 1;
+                fsk::jacobi_sweep(s->st, g, s->f.p, s->f.np, s->f.div, g.z0, z1);
+            }
+            std::swap(s->f.p, s->f.np);
+            s->p_ghost = 0;
+            s->prev_held = t == 1;
+            left -= t;
+            ++launches;
+        }
+        if (s->profiling) s->prof_launches[FS_STAGE_JACOBI] += launches;
     }
-    if (in_np) std::swap(s->f.p, s->f.np);
     s->last_sweeps += sweeps;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
 
-int residual_sync(fs_solver* s, const float* p, double* out)
+// sum r^2 over the whole grid (all ranks), binary64
+int residual_sync(fs_solver* s, bool previous, double* out)
 {
-    fsk::residual(s->st, s->g, p, s->f.div, s->d_partial, s->d_res);
+    if (s->world > 1) {
+        if (previous)
+            return fail(FS_ERR_STATE, "fs_residual(which=1) is not available on a z-slab");
+        int rc = ensure_p_ghosts(s, 1);
+        if (rc) return rc;
+    }
+    fsk::residual(s->st, s->g, previous ? s->f.np : s->f.p, s->f.div, s->d_partial, s->d_res);
     FS_HIP(hipGetLastError());
+    if (s->world > 1 && s->comm) {
+        Rccl* R = rccl();
+        FS_NCCL(R->AllReduce(s->d_res, s->d_res, 1, ncclDouble, ncclSum, s->comm, s->st));
+    }
     FS_HIP(hipMemcpyAsync(s->h_res, s->d_res, sizeof(double), hipMemcpyDeviceToHost, s->st));
     FS_HIP(hipStreamSynchronize(s->st));
+    if (s->world > 1 && !s->comm) {
+        int rc = s->xfn(s->xctx, FS_XCHG_SUM_F64, s->h_res, nullptr, nullptr, nullptr, sizeof(double));
+        if (rc) return fail(FS_ERR_COMM, "rank %d: the all-reduce callback returned %d", s->rank, rc);
+    }
     *out = *s->h_res;
     return FS_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-const char* fs_last_error(void) { return g_err.c_str(); }
-
-const char* fs_version(void) { return "fluidsolver_amd 0.1 (gfx950)"; }
-
-int fs_default_params(fs_params* p, int nx, int ny, int nz)
-{
-    if (!p) return fail(FS_ERR_INVALID, "fs_default_params: null params");
-    std::memset(p, 0, sizeof(*p));
-    p->nx = nx;
-    p->ny = ny;
-    p->nz = nz;
-    p->dt = 0.2f;
-    p->jacobi_iters = 30;
-    p->scheme = FS_SCHEME_MACCORMACK;
-    p->source_x = nx / 2.f;
-    p->source_y = 10.f;
-    p->source_z = nz / 2.f;
-    p->source_radius = 7.0f;
-    p->source_rho = 0.1f;
-    p->source_temperature = 2.f;
-    p->temperature_env = 0.f;
-    p->device = -1;
-    p->flags = 0;
-    p->tolerance = 0.f;
-    p->check_every = 8;
-    p->max_sweeps = 10000;
-    return FS_OK;
-}
-
-int fs_destroy(fs_solver* s)
-{
-    if (!s) return FS_OK;
-    (void)hipSetDevice(s->device);
-    if (s->st) (void)hipStreamSynchronize(s->st);
-    for (auto& pe : s->ev_pending) {
-        (void)hipEventDestroy(pe.a);
-        (void)hipEventDestroy(pe.b);
-    }
-    for (hipEvent_t e : s->ev_free) (void)hipEventDestroy(e);
-    for (float*& h : s->host)
-        if (h) (void)hipHostFree(h);
-    if (s->h_res) (void)hipHostFree(s->h_res);
-    if (s->h_flag) (void)hipHostFree(s->h_flag);
-    if (s->d_partial) (void)hipFree(s->d_partial);
-    if (s->d_res) (void)hipFree(s->d_res);
-    if (s->d_flag) (void)hipFree(s->d_flag);
-    if (s->pool) (void)hipFree(s->pool);
-    if (s->st) (void)hipStreamDestroy(s->st);
-    delete s;
-    return FS_OK;
-}
-
-int fs_create(const fs_params* p, fs_solver** out)
+int create_common(const fs_params* p, int rank, int world, const void* unique_id, fs_exchange_fn fn,
+                  void* ctx, fs_solver** out)
 {
     if (!p || !out) return fail(FS_ERR_INVALID, "fs_create: null argument");
     *out = nullptr;
@@ -225,6 +427,18 @@ int fs_create(const fs_params* p, fs_solver** out)
         return fail(FS_ERR_INVALID, "fs_create: unknown scheme %d", p->scheme);
     if (p->tolerance > 0.f && (p->check_every < 1 || p->max_sweeps < 1))
         return fail(FS_ERR_INVALID, "fs_create: convergence mode needs check_every, max_sweeps >= 1");
+    if (world < 1 || rank < 0 || rank >= world)
+        return fail(FS_ERR_INVALID, "fs_create_slab: rank %d of %d", rank, world);
+    if (world > 1 && !unique_id && !fn)
+        return fail(FS_ERR_INVALID, "fs_create_slab: neither an RCCL id nor an exchange function");
+    const int ghost = world > 1 ? 4 : 2;
+    // z-slabs: the first nz % world ranks get one plane more
+    const int base = p->nz / world, extra = p->nz % world;
+    const int nzl = base + (rank < extra ? 1 : 0);
+    const int z0 = rank * base + (rank < extra ? rank : extra);
+    if (world > 1 && base < ghost + 1)
+        return fail(FS_ERR_INVALID, "fs_create_slab: %d planes over %d ranks leaves slabs thinner than "
+                                    "the %d ghost planes + 1", p->nz, world, ghost);
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -243,18 +457,24 @@ int fs_create(const fs_params* p, fs_solver** out)
     if (!s) return fail(FS_ERR_INVALID, "fs_create: out of host memory");
     s->prm = *p;
     s->device = dev;
+    s->rank = rank;
+    s->world = world;
+    s->xfn = fn;
+    s->xctx = ctx;
     FsGrid& g = s->g;
     g.nx = p->nx;
     g.ny = p->ny;
     g.nz = p->nz;
-    g.z0 = 0;
-    g.nzl = p->nz;
-    g.ghost = 2;
-    g.wall_lo = g.wall_hi = 1;
+    g.z0 = z0;
+    g.nzl = nzl;
+    g.ghost = ghost;
+    g.wall_lo = rank == 0;
+    g.wall_hi = rank == world - 1;
     g.pitch = round_up(p->nx + 3, 16);
     long long plane = (long long)g.pitch * (p->ny + 3);
     long long planes = (long long)g.nzl + 1 + 2 * g.ghost;
-    if (plane * (p->nz + 4) >= (1LL << 31)) {
+    // kernels index with 32-bit element offsets relative to global plane 0
+    if (plane * ((long long)p->nz + g.ghost + 2) >= (1LL << 31)) {
         delete s;
         return fail(FS_ERR_INVALID, "fs_create: %dx%dx%d needs more than 2^31 elements per field",
                     p->nx, p->ny, p->nz);
@@ -297,8 +517,39 @@ int fs_create(const fs_params* p, fs_solver** out)
             break;
         }
         (void)hipMemsetAsync(s->d_flag, 0, sizeof(int), s->st);
-        // Solver.cu:993-995: T = temperature_env
-        if (p->temperature_env != 0.f) fsk::fill_interior(s->st, g, s->f.T, p->temperature_env);
+        // Solver.cu:993-995: T = temperature_env (ghost planes too: they hold the same constant)
+        if (p->temperature_env != 0.f) {
+            FsGrid all = g;
+            const int lo = g.wall_lo ? 0 : g.ghost, hi = g.wall_hi ? 0 : g.ghost;
+            all.nzl = g.nzl + lo + hi;
+            fsk::fill_interior(s->st, all, s->f.T - (ptrdiff_t)lo * g.plane, p->temperature_env);
+        }
+        if (world > 1) {
+            if (hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming) != hipSuccess) {
+                rc = fail(FS_ERR_HIP, "fs_create_slab: stream/event creation failed");
+                break;
+            }
+            if (unique_id) {
+                Rccl* R = rccl();
+                if (!R) {
+                    rc = fail(FS_ERR_COMM, "fs_create_slab: librccl.so.1 could not be loaded");
+                    break;
+                }
+                ncclUniqueId id;
+                std::memcpy(&id, unique_id, sizeof(id));
+                ncclResult_t ne = R->CommInitRank(&s->comm, world, id, rank);
+                if (ne != ncclSuccess) {
+                    s->comm = nullptr;
+                    rc = fail(FS_ERR_COMM, "fs_create_slab: ncclCommInitRank failed: %s", R->GetErrorString(ne));
+                    break;
+                }
+            }
+        }
+        // zero state: every ghost plane already equals its neighbour's owned plane
+        s->vel_ghost_ok = s->scal_ghost_ok = true;
+        s->p_ghost = g.ghost;
         if (hipStreamSynchronize(s->st) != hipSuccess || hipGetLastError() != hipSuccess) {
             rc = fail(FS_ERR_HIP, "fs_create: initialisation kernels failed");
             break;
@@ -314,6 +565,102 @@ int fs_create(const fs_params* p, fs_solver** out)
     return FS_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+const char* fs_last_error(void) { return g_err.c_str(); }
+
+const char* fs_version(void) { return "fluidsolver_amd 0.1 (gfx950)"; }
+
+int fs_default_params(fs_params* p, int nx, int ny, int nz)
+{
+    if (!p) return fail(FS_ERR_INVALID, "fs_default_params: null params");
+    std::memset(p, 0, sizeof(*p));
+    p->nx = nx;
+    p->ny = ny;
+    p->nz = nz;
+    p->dt = 0.2f;
+    p->jacobi_iters = 30;
+    p->scheme = FS_SCHEME_MACCORMACK;
+    p->source_x = nx / 2.f;
+    p->source_y = 10.f;
+    p->source_z = nz / 2.f;
+    p->source_radius = 7.0f;
+    p->source_rho = 0.1f;
+    p->source_temperature = 2.f;
+    p->temperature_env = 0.f;
+    p->device = -1;
+    p->flags = 0;
+    p->tolerance = 0.f;
+    p->check_every = 8;
+    p->max_sweeps = 10000;
+    return FS_OK;
+}
+
+int fs_destroy(fs_solver* s)
+{
+    if (!s) return FS_OK;
+    (void)hipSetDevice(s->device);
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    if (s->cs) (void)hipStreamSynchronize(s->cs);
+    if (s->comm && rccl()) (void)rccl()->CommDestroy(s->comm);
+    for (auto& pe : s->ev_pending) {
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
+    }
+    for (hipEvent_t e : s->ev_free) (void)hipEventDestroy(e);
+    if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+    for (float*& h : s->host)
+        if (h) (void)hipHostFree(h);
+    for (char*& b : s->h_stage)
+        if (b) (void)hipHostFree(b);
+    if (s->h_res) (void)hipHostFree(s->h_res);
+    if (s->h_flag) (void)hipHostFree(s->h_flag);
+    if (s->d_partial) (void)hipFree(s->d_partial);
+    if (s->d_res) (void)hipFree(s->d_res);
+    if (s->d_flag) (void)hipFree(s->d_flag);
+    if (s->pool) (void)hipFree(s->pool);
+    if (s->cs) (void)hipStreamDestroy(s->cs);
+    if (s->st) (void)hipStreamDestroy(s->st);
+    delete s;
+    return FS_OK;
+}
+
+int fs_create(const fs_params* p, fs_solver** out)
+{
+    return create_common(p, 0, 1, nullptr, nullptr, nullptr, out);
+}
+
+int fs_comm_unique_id(void* id)
+{
+    if (!id) return fail(FS_ERR_INVALID, "fs_comm_unique_id: null buffer");
+    Rccl* R = rccl();
+    if (!R) return fail(FS_ERR_COMM, "fs_comm_unique_id: librccl.so.1 could not be loaded");
+    ncclUniqueId u;
+    FS_NCCL(R->GetUniqueId(&u));
+    static_assert(sizeof(u) == FS_UNIQUE_ID_BYTES, "unique id size");
+    std::memcpy(id, &u, sizeof(u));
+    return FS_OK;
+}
+
+int fs_create_slab(const fs_params* p, int rank, int world, const void* unique_id,
+                   fs_exchange_fn fn, void* ctx, fs_solver** out)
+{
+    return create_common(p, rank, world, unique_id, fn, ctx, out);
+}
+
+int fs_slab_info(const fs_solver* s, int* rank, int* world, int* z0, int* nz_local)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    if (rank) *rank = s->rank;
+    if (world) *world = s->world;
+    if (z0) *z0 = s->g.z0;
+    if (nz_local) *nz_local = s->g.nzl;
+    return FS_OK;
+}
+
 int fs_stage_source(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
@@ -322,6 +669,7 @@ int fs_stage_source(fs_solver* s)
                  s->prm.source_rho, s->prm.source_temperature};
     StageScope sc(s, FS_STAGE_SOURCE, 1);
     fsk::source(s->st, s->g, src, s->f.rho, s->f.T);
+    s->scal_ghost_ok = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -332,6 +680,7 @@ int fs_stage_force(fs_solver* s)
     FS_HIP(hipSetDevice(s->device));
     StageScope sc(s, FS_STAGE_FORCE, 1);
     fsk::force_uy(s->st, s->g, s->f.uy, s->f.T, s->prm.dt, s->prm.temperature_env);
+    s->vel_ghost_ok = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -343,6 +692,8 @@ int fs_stage_advect(fs_solver* s)
     FsFields& f = s->f;
     const float dt = s->prm.dt;
     const int sc = s->prm.scheme;
+    int rc = ensure_advect_ghosts(s);
+    if (rc) return rc;
     // Solver.cu:1153-1158: all three components from the OLD velocity, then swap
     {
         StageScope ps(s, FS_STAGE_ADVECT_VELOCITY, fsk::advect_velocity_launches(s->g));
@@ -351,11 +702,16 @@ int fs_stage_advect(fs_solver* s)
     std::swap(f.ux, f.nux);
     std::swap(f.uy, f.nuy);
     std::swap(f.uz, f.nuz);
+    s->vel_ghost_ok = false;
+    if ((rc = ensure_velocity_ghosts(s))) return rc;
     // Solver.cu:1160-1164: T then rho with the NEW (advected, unprojected) velocity
-    StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 1);
-    fsk::advect_scalars(s->st, s->g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    {
+        StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 1);
+        fsk::advect_scalars(s->st, s->g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    }
     std::swap(f.T, f.nT);
     std::swap(f.rho, f.nrho);
+    s->scal_ghost_ok = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -364,8 +720,19 @@ int fs_stage_divergence(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     FS_HIP(hipSetDevice(s->device));
+    const FsGrid& g = s->g;
+    int zb = g.z0, ze = g.z0 + g.nzl;
+    if (s->world > 1) {
+        // the fused Jacobi pass recomputes intermediate sweeps on the ghost planes, so div is
+        // needed jacobi_block()-1 planes beyond the slab; the velocity ghosts provide it
+        int rc = ensure_velocity_ghosts(s);
+        if (rc) return rc;
+        const int ext = fsk::jacobi_block() - 1;
+        if (!g.wall_lo) zb -= ext;
+        if (!g.wall_hi) ze += ext;
+    }
     StageScope sc(s, FS_STAGE_DIVERGENCE, 1);
-    fsk::divergence(s->st, s->g, s->f.div, s->f.ux, s->f.uy, s->f.uz);
+    fsk::divergence(s->st, g, s->f.div, s->f.ux, s->f.uy, s->f.uz, zb, ze);
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -393,7 +760,7 @@ int fs_stage_project(fs_solver* s)
             rc = run_jacobi(s, n);
             if (rc) return rc;
             double r2 = 0.0;
-            rc = residual_sync(s, s->f.p, &r2);
+            rc = residual_sync(s, false, &r2);
             if (rc) return rc;
             if (r2 < (double)s->prm.tolerance) break;
         }
@@ -406,8 +773,11 @@ int fs_stage_gradient(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     FS_HIP(hipSetDevice(s->device));
+    int rc = ensure_p_ghosts(s, 1);
+    if (rc) return rc;
     StageScope sc(s, FS_STAGE_GRADIENT, 1);
     fsk::gradient(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->f.p);
+    s->vel_ghost_ok = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -512,6 +882,9 @@ int fs_field_upload(fs_solver* s, int field, const float* src)
     if (!s || !src || field < 0 || field >= FS_NUM_FIELDS)
         return fail(FS_ERR_INVALID, "fs_field_upload: bad argument");
     FS_HIP(hipSetDevice(s->device));
+    if (field <= FS_UZ) s->vel_ghost_ok = false;
+    if (field == FS_RHO || field == FS_T) s->scal_ghost_ok = false;
+    if (field == FS_P) s->p_ghost = 0;
     return copy_field(s, field, const_cast<float*>(src), false);
 }
 
@@ -521,7 +894,9 @@ int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layout)
         return fail(FS_ERR_INVALID, "fs_field_device: bad argument");
     *ptr = *field_slot(s, field);
     if (layout) {
-        field_dims(s, field, layout->dx, layout->dy, layout->dz);
+        layout->dx = s->g.nx + (field == FS_UX);
+        layout->dy = s->g.ny + (field == FS_UY);
+        layout->dz = s->g.nz + (field == FS_UZ);
         layout->z0 = s->g.z0;
         layout->nz_local = s->g.nzl + ((field == FS_UZ) ? 1 : 0);
         layout->ghost = s->g.ghost;
@@ -583,7 +958,7 @@ int fs_residual(fs_solver* s, int which, double* out)
         return fail(FS_ERR_STATE, "fs_residual: the iterate before the last sweep is not held "
                                   "(the last sweeps ran as one fused multi-sweep pass)");
     FS_HIP(hipSetDevice(s->device));
-    return residual_sync(s, which == 0 ? s->f.p : s->f.np, out);
+    return residual_sync(s, which == 1, out);
 }
 
 }  // extern "C"

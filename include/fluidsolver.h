@@ -100,6 +100,30 @@ FS_API int fs_default_params(fs_params* p, int nx, int ny, int nz);
 FS_API int fs_create(const fs_params* p, fs_solver** out);
 FS_API int fs_destroy(fs_solver* s);
 
+/* -- z-slab decomposition over the GPUs of one node, one process per GPU (no counterpart in
+      the reference, which is single-GPU).  Rank r owns cell planes [z0, z0 + nz_local) of the
+      global grid p->nz is cut into; every other call below then acts on that slab and the
+      host getters / fs_field_upload move the LOCAL planes only (nz_local planes, nz_local + 1
+      for FS_UZ).  Results are bit-identical to the single-GPU solver.
+      Transport, one of:
+        * unique_id != NULL: RCCL.  Rank 0 obtains 128 bytes from fs_comm_unique_id and hands
+          them to every rank (any out-of-band channel); halos travel as ncclSend/ncclRecv
+          between z-neighbours, the residual norm as ncclAllReduce.
+        * unique_id == NULL, fn != NULL: host-staged.  The library packs halos into pinned
+          host buffers and calls fn to move them (MPI, gloo, ...).  Used by the tests and as a
+          fallback; fn(ctx, FS_XCHG_HALO, send_lo, recv_lo, send_hi, recv_hi, bytes) must
+          deliver send_lo to rank-1 / send_hi to rank+1 and fill recv_* from them (a NULL pair
+          means no neighbour on that side); fn(ctx, FS_XCHG_SUM_F64, value, 0, 0, 0, 8) must
+          replace *(double*)value by its sum over all ranks.  Return 0 on success. -- */
+#define FS_UNIQUE_ID_BYTES 128
+enum { FS_XCHG_HALO = 0, FS_XCHG_SUM_F64 = 1 };
+typedef int (*fs_exchange_fn)(void* ctx, int op, void* send_lo, void* recv_lo, void* send_hi,
+                              void* recv_hi, size_t bytes);
+FS_API int fs_comm_unique_id(void* id /* FS_UNIQUE_ID_BYTES */);
+FS_API int fs_create_slab(const fs_params* p, int rank, int world, const void* unique_id,
+                          fs_exchange_fn fn, void* ctx, fs_solver** out);
+FS_API int fs_slab_info(const fs_solver* s, int* rank, int* world, int* z0, int* nz_local);
+
 /* -- stepping: replaces Solver::Update -> UpdateCuda (Solver.cu:1009-1114, 1132-1137)
       with VORT_CONFINE off and Project() on its Jacobi branch (Solver.cu:1178-1189) -- */
 FS_API int fs_step(fs_solver* s);

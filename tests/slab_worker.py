@@ -1,0 +1,90 @@
+"""Worker of the multi-rank slab tests: run under torch.distributed.run (one process per rank).
+
+    python -m torch.distributed.run --nproc-per-node W tests/slab_worker.py MODE NX NY NZ STEPS K [flags]
+
+Every rank drives its z-slab through the C ABI and the ranks' planes are gathered and compared
+bit-for-bit with the single-domain CPU oracle.  MODE = host (halos through host buffers and
+torch.distributed; ranks may share one GPU) or rccl (one GPU per rank).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import fluidsolver_amd as fs
+    from fluidsolver_amd.slab import SlabSolver
+    import oracle
+    from conftest import random_fields
+
+    mode = sys.argv[1]
+    nx, ny, nz, steps, k = (int(v) for v in sys.argv[2:7])
+    extra = sys.argv[7:]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(ndev, 1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kw = dict(jacobi_iters=k, source_y=min(10.0, ny / 3.0), source_radius=min(7.0, min(nx, ny, nz) / 4.0))
+    if "naive" in extra:
+        kw["flags"] = fs.FS_FLAG_JACOBI_NAIVE
+    if "converge" in extra:
+        kw.update(tolerance=1e-3, check_every=8, max_sweeps=400)
+    p = fs.default_params(nx, ny, nz, device=dev, **kw)
+    s = SlabSolver(p, rank, world, transport=mode).Initialize()
+    okw = {a: b for a, b in kw.items() if a not in ("flags", "tolerance", "check_every", "max_sweeps")}
+    o = oracle.Oracle(oracle.default_params(nx, ny, nz, **okw))
+    ok = True
+    if "random" in extra:
+        st = random_fields(nx, ny, nz, seed=5, vel_scale=1.5)
+        for fid, arr in st.items():
+            s.upload_global(fid, arr)
+            o.set(fid, arr)
+    for step in range(steps):
+        s.step()
+        if "converge" in extra:
+            sweeps = s.last_sweeps
+            res = s.residual(0)
+            o.stage("source"); o.stage("force"); o.stage("advect")
+            d = oracle.divergence(o.get(0), o.get(1), o.get(2))
+            pp = o.get(5)
+            for _ in range(sweeps):
+                pp, _r = oracle.jacobi(pp, d, want_r=False)
+            o.set(5, pp); o.set(6, d)
+            _, r = oracle.jacobi(pp, d)
+            want = oracle.sum_sq(r)
+            o.stage("gradient")
+            if abs(res - want) > 1e-5 * max(want, 1e-30) or not (res < 1e-3 or sweeps == 400):
+                print("rank %d step %d: residual %r vs oracle %r after %d sweeps" % (rank, step, res, want, sweeps))
+                ok = False
+        else:
+            o.step()
+        for fid in range(6):
+            got = s.gather(fid)
+            want = o.get(fid)
+            if got.shape != want.shape or not np.array_equal(got, want):
+                bad = np.argwhere(got != want) if got.shape == want.shape else []
+                print("rank %d step %d field %d differs (%d points, first %s)"
+                      % (rank, step + 1, fid, len(bad), bad[0] if len(bad) else got.shape))
+                ok = False
+        if not ok:
+            break
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    s.close()
+    o.close()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("SLAB_OK" if int(flag.item()) == 1 else "SLAB_FAIL")
+    sys.exit(0 if int(flag.item()) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,4 @@
 #!/bin/bash
 set -e -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 150 --timeout-method thread 2>&1 | tail -5
-FS_JACOBI_CFG=2 timeout -k 10 120 ./fluidsolver_amd/bin/fs_bench 512 80 5 2
-FS_JACOBI_CFG=2 timeout -k 10 120 ./fluidsolver_amd/bin/fs_bench 256 80 10 3
-FS_JACOBI_CFG=2 timeout -k 10 120 ./fluidsolver_amd/bin/fs_bench 64 20 100 10
+timeout -k 10 800 python -u -m pytest tests/test_slab_gpu.py -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -40
