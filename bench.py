@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--naive-jacobi", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--transport", choices=("rccl", "host"), default="rccl")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,19 +103,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one GPU per rank on the node; on a box with fewer GPUs than ranks (rehearsals) ranks share
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
 
     dist = None
     if world > 1:
+        # torch.distributed is the control plane only (unique-id hand-out, barriers, max over
+        # ranks); the halos travel inside the library over RCCL
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n = args.size
     flags = fs.FS_FLAG_JACOBI_NAIVE if args.naive_jacobi else 0
     if world == 1:
         p = fs.default_params(n, n, n, jacobi_iters=args.iters, scheme=args.scheme,
-                              device=local_rank, flags=flags)
+                              device=device, flags=flags)
         solver = fs.Solver(p).Initialize()
         cells_total = n ** 3
         workload = "%d^3 smoke plume, %d Jacobi sweeps/step, MacCormack, 1 GPU" % (n, args.iters)
@@ -122,11 +126,30 @@ def main():
     else:
         from fluidsolver_amd.slab import SlabSolver
         p = fs.default_params(n, n, n * world, jacobi_iters=args.iters, scheme=args.scheme,
-                              device=local_rank, flags=flags)
-        solver = SlabSolver(p, rank, world).Initialize()
+                              device=device, flags=flags)
+        transport = args.transport
+        solver = None
+        if transport == "rccl":
+            ok = 1
+            try:
+                solver = SlabSolver(p, rank, world, transport="rccl").Initialize()
+            except Exception as e:   # noqa: BLE001
+                print("bench.py rank %d: RCCL transport unavailable (%s)" % (rank, e), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                # every rank must use the same transport: all fall back to host-staged halos
+                if solver is not None:
+                    solver.close()
+                solver = None
+                transport = "host"
+        if solver is None:
+            solver = SlabSolver(p, rank, world, transport="host").Initialize()
         cells_total = n * n * n * world
-        workload = ("%dx%dx%d weak-scaling column, %d Jacobi sweeps/step, MacCormack, z-slabs on %d GPUs"
-                    % (n, n, n * world, args.iters, world))
+        workload = ("%dx%dx%d weak-scaling column, %d Jacobi sweeps/step, MacCormack, z-slabs on %d GPUs, "
+                    "halos over %s" % (n, n, n * world, args.iters, world,
+                                       "RCCL send/recv" if transport == "rccl" else "host buffers + gloo"))
         par = "z-slab x%d" % world
 
     def barrier():
@@ -147,7 +170,7 @@ def main():
     solver.profile(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -1,0 +1,87 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol the
+header declares, parameter defaults mirror the reference header, errors are reported (not
+swallowed) when no device is present, and the reference Renderer still compiles against
+include/Solver.h."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fluidsolver.h")).read()
+    return sorted(set(re.findall(r"FS_API\s+[\w\s\*]+?\b(fs_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(fs):
+    L = fs.load_library()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "libfluidsolver.so does not export %s" % n
+    from fluidsolver_amd import _capi
+    assert set(_capi.EXPORTED_SYMBOLS) <= set(names)
+
+
+def test_default_params_mirror_reference_header(fs):
+    """CuSolver/Include/Solver.h:58-81."""
+    p = fs.default_params(64, 128, 64)
+    assert (p.nx, p.ny, p.nz) == (64, 128, 64)
+    assert abs(p.dt - 0.2) < 1e-7 and p.jacobi_iters == 30 and p.scheme == fs.FS_SCHEME_MACCORMACK
+    assert (p.source_x, p.source_y, p.source_z, p.source_radius) == (32.0, 10.0, 32.0, 7.0)
+    assert abs(p.source_rho - 0.1) < 1e-7 and p.source_temperature == 2.0 and p.temperature_env == 0.0
+
+
+def test_bad_arguments_are_reported(fs):
+    L = fs.load_library()
+    h = C.c_void_p()
+    p = fs.default_params(0, 4, 4)
+    assert L.fs_create(C.byref(p), C.byref(h)) == -1 and b"outside" in L.fs_last_error()
+    p = fs.default_params(8, 8, 8, scheme=7)
+    assert L.fs_create(C.byref(p), C.byref(h)) == -1 and b"scheme" in L.fs_last_error()
+    assert L.fs_step(None) == -1
+    assert L.fs_field_size(None, 0) == 0
+
+
+def test_no_device_is_an_error_not_a_fallback(fs):
+    """Without a GPU fs_create must fail loudly; there is no CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(fs.FsError):
+        fs.Solver(fs.default_params(8, 8, 8)).Initialize()
+
+
+def test_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fluidsolver_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "fs_oracle" not in text, os.path.join(dirpath, f)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("g++") is None, reason="reference tree or g++ absent")
+def test_renderer_compiles_against_our_solver_header():
+    """The consumer of the boundary (Renderer/Source/FluidSolver.cpp:152-156, 207-214 and
+    main.cpp:11,17) compiles unchanged against include/Solver.h (syntax + semantics only: its
+    GLFW import library is a Windows binary, so it cannot be linked here)."""
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(REF, "ThirdParty/OpenGL/include"),
+           "-I", os.path.join(REF, "Renderer/Source")]
+    for src in ("Renderer/Source/FluidSolver.cpp", "Renderer/Source/main.cpp"):
+        r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-w", "-fpermissive", *inc, os.path.join(REF, src)],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_headless_host_program_links_the_shim():
+    exe = os.path.join(ROOT, "fluidsolver_amd", "bin", "fs_headless")
+    if not os.path.exists(exe):
+        pytest.skip("host programs not built")
+    out = subprocess.run(["ldd", exe], stdout=subprocess.PIPE, text=True).stdout
+    assert "libCuSolver.so" in out and "libfluidsolver.so" in out
