@@ -76,6 +76,7 @@ struct ZRange {
 struct Fld {
     __amdgpu_buffer_rsrc_t rs;
     unsigned c;
+    bool wide;   // plane * 4 does not fit a signed 24-bit multiply operand
 };
 
 __device__ __forceinline__ Fld make_fld(const float* f, const ZRange& zr, int pitch, int plane)
@@ -87,6 +88,7 @@ __device__ __forceinline__ Fld make_fld(const float* f, const ZRange& zr, int pi
     Fld F;
     F.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f + low), 0, bytes, 0x00020000);
     F.c = 8u + 8u * (unsigned)pitch - 4u * (unsigned)zr.lo * (unsigned)plane;
+    F.wide = plane >= (1 << 21);
     return F;
 }
 
@@ -107,7 +109,10 @@ __device__ __forceinline__ float gather_global(const Fld& F, Axis ax, Axis ay, A
     int iy = clampi(ay.i, -2, dy);
     int iz = clampi(az.i, zr.lo, zr.hi);
     const int sp = pitch * 4, sq = plane * 4;
-    unsigned vo = F.c + (unsigned)(ix * 4) + (unsigned)(iy * sp) + (unsigned)(iz * sq);
+    // 24-bit multiplies issue at full rate (v_mul_lo_u32 takes four passes); the row term always
+    // fits, the plane term fits for planes below 2^21 elements (the host sets F.wide otherwise)
+    unsigned vo = F.c + (unsigned)(ix * 4) + (unsigned)__mul24(iy, sp) +
+                  (unsigned)(F.wide ? iz * sq : __mul24(iz, sq));
     unsigned vo1 = vo + 4u;
     asm volatile("" : "+v"(vo1));
     float a = bload(F.rs, vo, 0);
@@ -136,6 +141,7 @@ struct Vel {
 // (Solver.cu:142-144) --------------------------------------------------------------------
 
 struct GlobalSampler {
+    static constexpr bool kHasGridStage = false;
     Fld ux, uy, uz;
     int nx, ny, pitch, plane;
     ZRange zc, zf;
@@ -174,12 +180,21 @@ struct BrickDims {
     static constexpr int LXY = LX * LY, N = LX * LY * LZ;
 };
 
+// One coordinate split on the fast path: integer part, fraction, and the byte offset the
+// integer part contributes to an LDS address.
+struct SplitL {
+    float f;
+    unsigned off;
+};
+
 template <class D>
 struct BrickSampler {
+    static constexpr bool kHasGridStage = true;
     GlobalSampler G;
     const float* lds;    // 3 * D::N floats: ux, uy, uz
     int ox, oy, oz;      // global index of LDS element 0 along each axis
 
+    // ---- general path: literal split, per-gather choice between LDS and global memory ----
     __device__ __forceinline__ float gather(int which, const Fld& F, Axis ax, Axis ay, Axis az,
                                             int dx, int dy, const ZRange& zr) const
     {
@@ -187,7 +202,7 @@ struct BrickSampler {
         bool in = ((unsigned)lx <= (unsigned)(D::LX - 2)) & ((unsigned)ly <= (unsigned)(D::LY - 2)) &
                   ((unsigned)lz <= (unsigned)(D::LZ - 2));
         if (__builtin_expect(in, 1)) {
-            const float* q = lds + which * D::N + lx + ly * D::LX + lz * D::LXY;
+            const float* q = lds + which * D::N + lx + __mul24(ly, D::LX) + __mul24(lz, D::LXY);
             float a = q[0], b = q[1], c = q[D::LX], d = q[D::LX + 1];
             const float* q2 = q + D::LXY;
             float e = q2[0], f = q2[1], g = q2[D::LX], h = q2[D::LX + 1];
@@ -196,7 +211,7 @@ struct BrickSampler {
         return gather_global(F, ax, ay, az, dx, dy, zr, G.pitch, G.plane);
     }
     template <bool HALO>
-    __device__ __forceinline__ float3 vel(float3 p, int& bad) const
+    __device__ __forceinline__ float3 vel_general(float3 p, int& bad) const
     {
         Axis x0 = split_axis(p.x - 0.f), xh = split_axis(p.x - 0.5f);
         Axis y0 = split_axis(p.y - 0.f), yh = split_axis(p.y - 0.5f);
@@ -208,6 +223,102 @@ struct BrickSampler {
         u.x = gather(0, G.ux, x0, yh, zh, G.nx + 1, G.ny, G.zc);
         u.y = gather(1, G.uy, xh, y0, zh, G.nx, G.ny + 1, G.zc);
         u.z = gather(2, G.uz, xh, yh, z0, G.nx, G.ny, G.zf);
+        return u;
+    }
+
+    // ---- fast path, taken when it holds for every lane of the wave ----
+    // For a coordinate c >= 0 the reference split (Solver.cu:58-82) is ix = floor(c),
+    // fx = c - floor(c): truncation equals floor and the c < -1e-6 fix-up cannot fire.
+    // `scale`/`bias` turn ix into the byte offset of that axis inside the brick; the unsigned
+    // compare against `limit` checks that taps ix and ix+1 are both inside it.
+    __device__ __forceinline__ SplitL split_fast(float c, int scale, int bias, unsigned limit,
+                                                 bool& ok) const
+    {
+        float fl = floorf(c);
+        SplitL s;
+        s.f = c - fl;
+        s.off = (unsigned)(__mul24((int)fl, scale) + bias);
+        ok &= s.off <= limit;
+        return s;
+    }
+    __device__ __forceinline__ float gather_fast(int which, const SplitL& sx, const SplitL& sy,
+                                                 const SplitL& sz) const
+    {
+        const char* base = reinterpret_cast<const char*>(lds + which * D::N);
+        const float* q = reinterpret_cast<const float*>(base + (sx.off + sy.off + sz.off));
+        float a = q[0], b = q[1], c = q[D::LX], d = q[D::LX + 1];
+        const float* q2 = q + D::LXY;
+        float e = q2[0], f = q2[1], g = q2[D::LX], h = q2[D::LX + 1];
+        return trilerp8(a, b, c, d, e, f, g, h, sx.f, sy.f, sz.f);
+    }
+    template <bool HALO>
+    __device__ __forceinline__ float3 vel(float3 p, int& bad) const
+    {
+        const float xh = p.x - 0.5f, yh = p.y - 0.5f, zh = p.z - 0.5f;
+        // all six coordinates are >= 0 iff the three shifted ones are
+        bool ok = fminf(fminf(xh, yh), zh) >= 0.f;
+        constexpr int SX = 4, SY = 4 * D::LX, SZ = 4 * D::LXY;
+        constexpr unsigned LIMX = SX * (D::LX - 2), LIMY = SY * (D::LY - 2), LIMZ = SZ * (D::LZ - 2);
+        const int bx = -ox * SX, by = -oy * SY, bz = -oz * SZ;
+        SplitL x0 = split_fast(p.x, SX, bx, LIMX, ok), x5 = split_fast(xh, SX, bx, LIMX, ok);
+        SplitL y0 = split_fast(p.y, SY, by, LIMY, ok), y5 = split_fast(yh, SY, by, LIMY, ok);
+        SplitL z0 = split_fast(p.z, SZ, bz, LIMZ, ok), z5 = split_fast(zh, SZ, bz, LIMZ, ok);
+        if (!__all(ok)) return vel_general<HALO>(p, bad);
+        if (HALO) {
+            // ghost-plane check on the plane indices recovered from the offsets
+            int iz5 = (int)(z5.off / (unsigned)SZ) + oz, iz0 = (int)(z0.off / (unsigned)SZ) + oz;
+            bad |= (iz5 < G.zc.chk_lo) | (iz5 > G.zc.chk_hi) | (iz0 < G.zf.chk_lo) | (iz0 > G.zf.chk_hi);
+        }
+        float3 u;
+        u.x = gather_fast(0, x0, y5, z5);
+        u.y = gather_fast(1, x5, y0, z5);
+        u.z = gather_fast(2, x5, y5, z0);
+        return u;
+    }
+
+    // ---- velocity at a sample point of the grid (first stage of the first RK4) ----
+    // At a grid sample point every gather coordinate is an integer (weight 0) or an integer
+    // plus one half (weight .5).  A weight-0 lerp returns its first operand for finite data
+    // (a*1 + b*0), so those taps are not read; the weight-.5 lerps run through lerp1 as usual.
+    // MX/MY/MZ: the axis has weight .5.  q addresses the lower taps.
+    template <bool MX, bool MY, bool MZ>
+    static __device__ __forceinline__ float gather_grid(const float* q)
+    {
+        auto X = [](const float* r) { return MX ? lerp1(r[0], r[1], 0.5f) : r[0]; };
+        float v00 = X(q);
+        float l1 = MY ? lerp1(v00, X(q + D::LX), 0.5f) : v00;
+        if (!MZ) return l1;
+        float v01 = X(q + D::LXY);
+        float l2 = MY ? lerp1(v01, X(q + D::LXY + D::LX), 0.5f) : v01;
+        return lerp1(l1, l2, 0.5f);
+    }
+    // DIR = 0 cell centre, 1/2/3 the x/y/z face of cell (i,j,k); the point is inside the brick.
+    template <int DIR>
+    __device__ __forceinline__ float3 vel_grid(int i, int j, int k) const
+    {
+        // sample offsets of the point: 0 on the face axis, .5 elsewhere (Solver.cu:381-383)
+        constexpr bool px = DIR != 1, py = DIR != 2, pz = DIR != 3;   // true = offset .5
+        const float* c = lds + (i - ox) + (j - oy) * D::LX + (k - oz) * D::LXY;
+        // array a has offset 0 on its own axis and .5 on the others; on an axis where point and
+        // array offsets agree the coordinate is the integer index (weight 0); where the point has
+        // 0 and the array .5 it is index - .5 (lower tap index-1); where the point has .5 and the
+        // array 0 it is index + .5 (lower tap index)
+        float3 u;
+        {   // ux: array offsets (0, .5, .5)
+            constexpr bool mx = px, my = !py, mz = !pz;
+            const float* q = c - (my ? D::LX : 0) - (mz ? D::LXY : 0);
+            u.x = gather_grid<mx, my, mz>(q);
+        }
+        {   // uy: (.5, 0, .5)
+            constexpr bool mx = !px, my = py, mz = !pz;
+            const float* q = c + D::N - (mx ? 1 : 0) - (mz ? D::LXY : 0);
+            u.y = gather_grid<mx, my, mz>(q);
+        }
+        {   // uz: (.5, .5, 0)
+            constexpr bool mx = !px, my = !py, mz = pz;
+            const float* q = c + 2 * D::N - (mx ? 1 : 0) - (my ? D::LX : 0);
+            u.z = gather_grid<mx, my, mz>(q);
+        }
         return u;
     }
 };
@@ -267,10 +378,10 @@ __device__ __forceinline__ void stage_velocity(float* lds, const Vel& v, int ox,
 // Solver.cu:139-161.  (0.5f*dt) is formed first, then scales each component
 // (Math.cuh:80-86); the final update is  pos - (dt * sum) / 6  with a true division.
 template <bool HALO, class S>
-__device__ __forceinline__ float3 rk4(const S& s, float3 pos, float dt, int& bad)
+__device__ __forceinline__ float3 rk4(const S& s, float3 pos, float dt, int& bad, const float3* first)
 {
     float hdt = 0.5f * dt;
-    float3 u1 = s.template vel<HALO>(pos, bad);
+    float3 u1 = first ? *first : s.template vel<HALO>(pos, bad);
     float3 p1 = make_float3(pos.x - hdt * u1.x, pos.y - hdt * u1.y, pos.z - hdt * u1.z);
     float3 u2 = s.template vel<HALO>(p1, bad);
     float3 p2 = make_float3(pos.x - hdt * u2.x, pos.y - hdt * u2.y, pos.z - hdt * u2.z);
@@ -285,12 +396,14 @@ __device__ __forceinline__ float3 rk4(const S& s, float3 pos, float dt, int& bad
 }
 
 // Solver.cu:163-169 (MAC) or the plain RK4 trace of Solver.cu:396.
+// `first`: velocity at pos when the caller already has it (pos is a grid sample point).
 template <bool MAC, bool HALO, class S>
-__device__ __forceinline__ float3 backtrace(const S& s, float3 pos, float dt, int& bad)
+__device__ __forceinline__ float3 backtrace(const S& s, float3 pos, float dt, int& bad,
+                                            const float3* first = nullptr)
 {
-    float3 pred = rk4<HALO>(s, pos, dt, bad);
+    float3 pred = rk4<HALO>(s, pos, dt, bad, first);
     if (!MAC) return pred;
-    float3 refl = rk4<HALO>(s, pred, -dt, bad);
+    float3 refl = rk4<HALO>(s, pred, -dt, bad, nullptr);
     return make_float3(pred.x + (pos.x - refl.x) / 2.f, pred.y + (pos.y - refl.y) / 2.f,
                        pred.z + (pos.z - refl.z) / 2.f);
 }
@@ -304,7 +417,13 @@ __device__ __forceinline__ float advect_component(const S& s, const GlobalSample
     pos.x = (float)i + (DIR == 1 ? 0.f : 0.5f);
     pos.y = (float)j + (DIR == 2 ? 0.f : 0.5f);
     pos.z = (float)k + (DIR == 3 ? 0.f : 0.5f);
-    float3 c = backtrace<MAC, HALO>(s, pos, dt, bad);
+    float3 c;
+    if constexpr (S::kHasGridStage) {
+        float3 u1 = s.template vel_grid<DIR>(i, j, k);
+        c = backtrace<MAC, HALO>(s, pos, dt, bad, &u1);
+    } else {
+        c = backtrace<MAC, HALO>(s, pos, dt, bad);
+    }
     Axis ax = split_axis(c.x - (DIR == 1 ? 0.f : 0.5f));
     Axis ay = split_axis(c.y - (DIR == 2 ? 0.f : 0.5f));
     Axis az = split_axis(c.z - (DIR == 3 ? 0.f : 0.5f));
@@ -454,7 +573,8 @@ k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const 
         const int i = X0 + lx, j = Y0 + ly, k = Z0 + lz;
         if (i >= B.x0 + B.nx || j >= B.y0 + B.ny || k >= B.z0 + B.nz) continue;
         float3 pos = make_float3((float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f);
-        float3 c = backtrace<MAC, HALO>(S, pos, dt, bad);
+        float3 u1 = S.template vel_grid<0>(i, j, k);
+        float3 c = backtrace<MAC, HALO>(S, pos, dt, bad, &u1);
         Axis ax = split_axis(c.x - 0.5f), ay = split_axis(c.y - 0.5f), az = split_axis(c.z - 0.5f);
         if (HALO) bad |= (az.i < v.zc.chk_lo) | (az.i > v.zc.chk_hi);
         const int o = i + j * v.pitch + k * v.plane;

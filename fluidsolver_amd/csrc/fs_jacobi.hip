@@ -52,7 +52,19 @@ struct TbArgs {
     int zin_lo, zin_hi;  // level-0 planes that may be read: [zin_lo, zin_hi)
     int zout_lo, zout_hi;// planes to produce
     int lz;              // output planes per workgroup along z
+    int tiles_x, tiles_y, nblocks;
+    int order;           // 0: plain block order, 1: XCD-contiguous (z-chunk, y, x) order
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs, so ids b and b+8 share an L2.  Give each
+// XCD one contiguous run of logical ids (bijective for any count): tiles that share halo rows
+// and columns then run on one XCD at about the same time and meet in its L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int nb)
+{
+    int q = nb >> 3, r = nb & 7;
+    int xcd = b & 7, loc = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
 
 // x / 6 rounded to nearest, bit-identical to the IEEE division for every finite x whose
 // quotient is a normal number: q = RN(x*c) with c = RN(1/6) is within one ulp of x/6, the
@@ -73,10 +85,12 @@ __device__ __forceinline__ bool div6_needs_slow(float q)
 }
 
 // Per-thread registers of the march: for level t, a = plane n-t-2, b = plane n-t-1 and
-// cc = plane n-t of that level; dv[t] = div of plane n-t; nxt_* = loads in flight.
+// cc = plane n-t of that level; dv[t] = div of plane n-t; q_p / q_d = loads in flight, two
+// march steps deep: slot n & 1 holds p of plane n and div of plane n-1 when step n starts and is
+// refilled by step n with p of plane n+2 and div of plane n+1.
 template <int T, int CPT>
 struct TbRegs {
-    f4 a[T][CPT], b[T][CPT], cc[T][CPT], dv[T + 1][CPT], nxt_p[CPT], nxt_d[CPT];
+    f4 a[T][CPT], b[T][CPT], cc[T][CPT], dv[T + 1][CPT], q_p[2][CPT], q_d[2][CPT];
 };
 
 // Per-thread constants of the march.
@@ -100,31 +114,34 @@ struct TbRange {
 // One march step.  EDGE = false is the steady state: every level is active, no plane touched
 // is a z wall, the next plane exists and the stored plane is in range, so the body is branch-free
 // apart from the rare slow-division path.
-template <int T, int NTY, int CPT, bool EDGE>
+template <int T, int NTY, int CPT, bool EDGE, int PH>
 __device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L,
                                         const TbArgs& A, const TbRange& Z, f4* lds)
 {
+    // PH == n & 1: selects the load slot and the LDS buffer statically
     constexpr int H = NTY * CPT;
-    const int cur = n & 1, prv = cur ^ 1;
+    constexpr int cur = PH, prv = PH ^ 1;
     f4* lcur = lds + cur * (T * H * kW4) + L.tx;
     const f4* lprv = lds + prv * (T * H * kW4) + L.tx;
 
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        R.cc[0][c] = R.nxt_p[c];
-        R.dv[1][c] = R.nxt_d[c];
+        R.cc[0][c] = R.q_p[PH][c];
+        R.dv[1][c] = R.q_d[PH][c];
+    }
+    if (!EDGE || n + 2 < Z.n_end) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c)
+            R.q_p[PH][c] = *reinterpret_cast<const f4*>(A.p + L.ld_off[c] + (n + 2) * A.plane);
     }
     if (!EDGE || n + 1 < Z.n_end) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c)
-            R.nxt_p[c] = *reinterpret_cast<const f4*>(A.p + L.ld_off[c] + (n + 1) * A.plane);
+            R.q_d[PH][c] = *reinterpret_cast<const f4*>(A.div + L.ld_off[c] + (n + 1) * A.plane);
     }
     if (!EDGE || n < Z.n_end) {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            R.nxt_d[c] = *reinterpret_cast<const f4*>(A.div + L.ld_off[c] + n * A.plane);
-            lcur[L.row[c] * kW4] = R.cc[0][c];
-        }
+        for (int c = 0; c < CPT; ++c) lcur[L.row[c] * kW4] = R.cc[0][c];
         if (EDGE && n == 0) {   // plane 0: the clamped z-1 neighbour is the plane itself
 #pragma unroll
             for (int c = 0; c < CPT; ++c) R.b[0][c] = R.cc[0][c];
@@ -201,7 +218,13 @@ k_jacobi_tb(TbArgs A)
     TbLane<CPT> L;
     L.tx = threadIdx.x;
     const int ty = threadIdx.y;
-    const int x = (int)blockIdx.x * kBX - kHaloX + 4 * L.tx;    // first cell of the column
+    // tile (bx, by) and z chunk bz of this workgroup
+    const int lid = A.order ? xcd_contiguous((int)blockIdx.x, A.nblocks) : (int)blockIdx.x;
+    const int bz = lid / (A.tiles_x * A.tiles_y);
+    const int rem = lid - bz * (A.tiles_x * A.tiles_y);
+    const int by = rem / A.tiles_x;
+    const int bx = rem - by * A.tiles_x;
+    const int x = bx * kBX - kHaloX + 4 * L.tx;                  // first cell of the column
     const bool x_in = x >= 0 && x < A.nx;                        // nx % 4 == 0: all four or none
     L.at_left = x == 0;
     L.at_right = x + 4 == A.nx;
@@ -210,7 +233,7 @@ k_jacobi_tb(TbArgs A)
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const int row = ty + c * NTY;
-        const int y = (int)blockIdx.y * BY - T + row;
+        const int y = by * BY - T + row;
         const bool in = x_in && y >= 0 && y < A.ny;
         L.row[c] = row;
         // clamped y-neighbours (Solver.cu:435-436): a wall row reads itself
@@ -222,7 +245,7 @@ k_jacobi_tb(TbArgs A)
     }
 
     TbRange Z;
-    Z.out_lo = A.zout_lo + (int)blockIdx.z * A.lz;
+    Z.out_lo = A.zout_lo + bz * A.lz;
     Z.out_hi = min(Z.out_lo + A.lz, A.zout_hi);
     Z.n_begin = max(Z.out_lo - T, A.zin_lo);
     Z.n_end = min(Z.out_hi + T, A.zin_hi);
@@ -237,22 +260,39 @@ k_jacobi_tb(TbArgs A)
     for (int t = 0; t <= T; ++t)
 #pragma unroll
         for (int c = 0; c < CPT; ++c) R.dv[t][c] = zero;
+    // prime the two load slots: p of planes n_begin and n_begin + 1, div of plane n_begin
+    {
+        const int s0 = Z.n_begin & 1;
+        const bool two = Z.n_begin + 1 < Z.n_end;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        R.nxt_d[c] = zero;
-        R.nxt_p[c] = *reinterpret_cast<const f4*>(A.p + L.ld_off[c] + Z.n_begin * A.plane);
+        for (int c = 0; c < CPT; ++c) {
+            const f4 p0 = *reinterpret_cast<const f4*>(A.p + L.ld_off[c] + Z.n_begin * A.plane);
+            const f4 d0 = *reinterpret_cast<const f4*>(A.div + L.ld_off[c] + Z.n_begin * A.plane);
+            f4 p1 = zero;
+            if (two) p1 = *reinterpret_cast<const f4*>(A.p + L.ld_off[c] + (Z.n_begin + 1) * A.plane);
+            R.q_p[0][c] = s0 ? p1 : p0;
+            R.q_p[1][c] = s0 ? p0 : p1;
+            R.q_d[0][c] = s0 ? d0 : zero;
+            R.q_d[1][c] = s0 ? zero : d0;
+        }
     }
 
-    // steady range: all levels active (n-T >= n_begin), no z wall among planes n-T..n+1 and
-    // n+1 still readable, stored plane n-T inside [out_lo, out_hi)
+    // steady range: all levels active (n-T >= n_begin), no z wall among planes n-T..n+2 and
+    // plane n+2 still readable, stored plane n-T inside [out_lo, out_hi)
     const int steady_lo = max(Z.n_begin + T + 1, Z.out_lo + T);
-    const int steady_hi = min(Z.n_end - 1, Z.out_hi + T);
+    const int steady_hi = min(Z.n_end - 2, Z.out_hi + T);
     const int last = Z.n_end + T;
     int n = Z.n_begin;
-    for (; n < min(steady_lo, last); ++n) tb_step<T, NTY, CPT, true>(n, R, L, A, Z, lds);
-#pragma unroll 3
-    for (; n < steady_hi; ++n) tb_step<T, NTY, CPT, false>(n, R, L, A, Z, lds);
-    for (; n < last; ++n) tb_step<T, NTY, CPT, true>(n, R, L, A, Z, lds);
+    auto edge_step = [&](int m) {
+        if (m & 1) tb_step<T, NTY, CPT, true, 1>(m, R, L, A, Z, lds);
+        else tb_step<T, NTY, CPT, true, 0>(m, R, L, A, Z, lds);
+    };
+    for (; n < last && (n < steady_lo || (n & 1)); ++n) edge_step(n);
+    for (; n + 1 < steady_hi; n += 2) {
+        tb_step<T, NTY, CPT, false, 0>(n, R, L, A, Z, lds);
+        tb_step<T, NTY, CPT, false, 1>(n + 1, R, L, A, Z, lds);
+    }
+    for (; n < last; ++n) edge_step(n);
 }
 
 // plain one-sweep kernel (any nx): one cell per thread
@@ -294,6 +334,15 @@ int tb_config()
     return cfg;
 }
 
+int tb_order()
+{
+    static int v = [] {
+        const char* e = getenv("FS_JACOBI_ORDER");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+
 int tb_chunk_planes()
 {
     static int v = [] {
@@ -309,13 +358,33 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
     constexpr int H = NTY * CPT, BY = H - 2 * T;
     int tiles = cdiv(g.nx, kBX) * cdiv(g.ny, BY);
     int nout = A.zout_hi - A.zout_lo;
-    // enough z chunks to give every CU a few workgroups, but chunks of at least 16 planes
-    int want = cdiv(256 * 4, tiles);
-    int chunks = max(1, min(want, cdiv(nout, 16)));
+    // Cut z into chunks so that the workgroups fill whole rounds of the chip.  A workgroup costs
+    // (planes + 2T) march steps (T planes of ramp-up and drain at each chunk edge), and with
+    // `slots` workgroups resident at once the launch takes ceil(blocks / slots) rounds.
+    constexpr int lds_bytes = 2 * T * H * kW4 * 16;
+    constexpr int per_cu_lds = 163840 / lds_bytes;
+    constexpr int per_cu_waves = 16 / (kW4 * NTY / 64 > 16 ? 16 : kW4 * NTY / 64);   // <= 4 waves/SIMD at ~128 VGPRs
+    const int slots = 256 * max(1, min(per_cu_lds, per_cu_waves));
+    int chunks = 1;
+    long best = -1;
+    for (int c = 1; c <= max(1, nout / 8); ++c) {
+        long rounds = cdiv(tiles * c, slots);
+        long cost = rounds * (cdiv(nout, c) + 2 * T);
+        // a launch that leaves CUs idle in its only round pays for the idle ones too
+        if (tiles * c < slots) cost = cost * slots / (tiles * c);
+        if (best < 0 || cost < best) {
+            best = cost;
+            chunks = c;
+        }
+    }
     A.lz = cdiv(nout, chunks);
     if (tb_chunk_planes() > 0) A.lz = min(nout, tb_chunk_planes());
     chunks = cdiv(nout, A.lz);
-    dim3 grid(cdiv(g.nx, kBX), cdiv(g.ny, BY), chunks), block(kW4, NTY);
+    A.tiles_x = cdiv(g.nx, kBX);
+    A.tiles_y = cdiv(g.ny, BY);
+    A.nblocks = A.tiles_x * A.tiles_y * chunks;
+    A.order = tb_order();
+    dim3 grid(A.nblocks), block(kW4, NTY);
     hipLaunchKernelGGL((k_jacobi_tb<T, NTY, CPT>), grid, block, 0, st, A);
 }
 
@@ -328,6 +397,7 @@ void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const
     A.p = p - zoff;
     A.np = np - zoff;
     A.div = div - zoff;
+    if (getenv("FS_JACOBI_ABLATE_DIV")) A.div = A.p;   // timing experiment: div loads alias p (results wrong)
     A.nx = g.nx; A.ny = g.ny; A.nz = g.nz;
     A.pitch = g.pitch; A.plane = g.plane;
     A.zin_lo = zin_lo; A.zin_hi = zin_hi;

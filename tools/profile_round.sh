@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun):
+#   tools/profile_round.sh <tag>        e.g. r01
+# 1. kernel-trace --stats of the default bench.py run (512^3, 80 sweeps)
+# 2. separate --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass) of the headless C++ bench
+# Output under gpurun_out/prof_<tag>/ ; tools/pmc_to_json.py turns it into profiles/.
+set -e -o pipefail
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+rm -rf $OUT && mkdir -p $OUT
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench512 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+B=./fluidsolver_amd/bin/fs_bench
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $B 512 80 2 1 > $OUT/pmc_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $B 512 80 2 1 > $OUT/pmc_write.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o p -- $B 512 80 2 1 > $OUT/pmc_sq.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o p -- $B 512 80 2 1 > $OUT/pmc_l2.log 2>&1
+tail -1 $OUT/stats.log | cut -c1-400
+find $OUT -name "*.csv" | head -20

@@ -1,7 +1,8 @@
 #!/bin/bash
 set -e -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-echo "== N=1 plain"
-timeout -k 10 300 python -u bench.py --size 256 --steps 5 --warmup 2 --no-cpu-baseline
-echo "== N=2 on one GPU (RCCL expected to refuse a duplicate GPU -> host fallback)"
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29700 bench.py --gpus 2 --size 128 --steps 3 --warmup 1 2>&1 | tail -25
+timeout -k 10 300 python -u -m pytest tests/test_parity_gpu.py -m gpu -x -q --timeout 150 --timeout-method thread -k "advect or stage or full_step or quirk" 2>&1 | tail -3
+for g in 0 2 1; do
+echo "== global mask $g"
+FS_ADVECT_GLOBAL=$g timeout -k 10 120 ./fluidsolver_amd/bin/fs_bench 512 8 3 1
+done
