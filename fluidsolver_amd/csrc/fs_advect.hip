@@ -176,6 +176,7 @@ struct GlobalSampler {
 // array: entries outside the array's own extent are 0, like the reference's sample outside.
 template <int BX, int BY, int BZ, int H>
 struct BrickDims {
+    static_assert(BX % 4 == 0 && (H + 1) % 4 == 0, "brick rows are staged as aligned 16-byte quads");
     static constexpr int LX = BX + 2 * H + 1, LY = BY + 2 * H + 1, LZ = BZ + 2 * H + 1;
     static constexpr int LXY = LX * LY, N = LX * LY * LZ;
 };
@@ -329,35 +330,48 @@ __device__ __forceinline__ void stage_array(float* dst, const float* __restrict_
                                             int oz, int dx, int dy, int zd_lo, int zd_hi, int pitch,
                                             int plane)
 {
-    // Raw buffer over the array's data box: an element outside the box gets an offset past
-    // the end of the buffer, for which the hardware returns 0.  All loads of a batch are
-    // issued before the first LDS write, so their latencies overlap.
+    // Rows are read as aligned 16-byte quads (the brick's x origin is one element past a
+    // 16-byte boundary, so quad 0 starts at lx = -1 and that element is dropped).  Raw buffer
+    // over the array's data box: a quad of a row outside the box gets an offset past the end of
+    // the buffer, for which the hardware returns 0; elements left or right of the array's x
+    // extent are zeroed one by one.  All loads are issued before the first LDS write.
+    typedef float f4 __attribute__((ext_vector_type(4)));
     const float* base = src + (long)zd_lo * plane;
     const unsigned bytes = zd_hi > zd_lo ? (unsigned)(zd_hi - zd_lo) * (unsigned)plane * 4u : 0u;
     __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
-    constexpr int PER = (D::N + THREADS - 1) / THREADS;
-    constexpr int BATCH = 8;
-#pragma unroll 1
-    for (int u0 = 0; u0 < PER; u0 += BATCH) {
-        float vals[BATCH];
+    constexpr int Q = (D::LX + 4) / 4;            // quads per row: lx = -1 .. 4Q-2
+    constexpr int NQ = Q * D::LY * D::LZ;
+    constexpr int PER = (NQ + THREADS - 1) / THREADS;
+    f4 vals[PER];
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            int e = threadIdx.x + (u0 + u) * THREADS;
-            int lz = e / D::LXY;
-            int r = e - lz * D::LXY;
-            int ly = r / D::LX;
-            int lx = r - ly * D::LX;
-            int x = ox + lx, y = oy + ly, z = oz + lz;
-            bool ok = ((unsigned)x < (unsigned)dx) & ((unsigned)y < (unsigned)dy) & (z >= zd_lo) &
-                      (z < zd_hi) & (e < D::N);
-            unsigned off = (unsigned)(x + y * pitch + (z - zd_lo) * plane) * 4u;
-            vals[u] = bload(rs, ok ? off : 0xfffffffcu, 0);
-        }
+    for (int u = 0; u < PER; ++u) {
+        int e = threadIdx.x + u * THREADS;
+        int r = e / Q;
+        int q = e - r * Q;
+        int lz = r / D::LY;
+        int ly = r - lz * D::LY;
+        int x = ox - 1 + 4 * q, y = oy + ly, z = oz + lz;
+        bool ok = ((unsigned)y < (unsigned)dy) & (z >= zd_lo) & (z < zd_hi) & (e < NQ);
+        unsigned off = (unsigned)(x + y * pitch + (z - zd_lo) * plane) * 4u;
+        f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? off : 0xfffffff0u), 0, 0));
+        v.x = (unsigned)(x + 0) < (unsigned)dx ? v.x : 0.f;
+        v.y = (unsigned)(x + 1) < (unsigned)dx ? v.y : 0.f;
+        v.z = (unsigned)(x + 2) < (unsigned)dx ? v.z : 0.f;
+        v.w = (unsigned)(x + 3) < (unsigned)dx ? v.w : 0.f;
+        vals[u] = v;
+    }
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            int e = threadIdx.x + (u0 + u) * THREADS;
-            if (e < D::N) dst[e] = vals[u];
+    for (int u = 0; u < PER; ++u) {
+        int e = threadIdx.x + u * THREADS;
+        if (e < NQ) {
+            int r = e / Q;
+            int q = e - r * Q;
+            float* d = dst + r * D::LX + 4 * q - 1;
+            if (q > 0) d[0] = vals[u].x;
+            d[1] = vals[u].y;
+            d[2] = vals[u].z;
+            if (4 * q + 2 < D::LX) d[3] = vals[u].w;
         }
     }
 }
@@ -630,8 +644,7 @@ k_advect_scalars_global(const float* __restrict__ T, float* __restrict__ nT,
 }
 
 // FS_ADVECT_GLOBAL (timing experiments): bit 0 = velocity on the global path, bit 1 = scalars
-// on the LDS-brick path.  Default: velocity through LDS bricks (three back-traces share one
-// staged brick), scalars on the global path (one back-trace does not repay the staging).
+// on the global path.  Default: both through LDS bricks.
 int path_mask()
 {
     static int v = [] {
@@ -641,7 +654,7 @@ int path_mask()
     return v;
 }
 bool use_global_path() { return (path_mask() & 1) != 0; }
-bool scalars_use_lds() { return (path_mask() & 2) != 0; }
+bool scalars_use_lds() { return (path_mask() & 2) == 0; }
 
 #define FS_DISPATCH_MH(mac, halo, CALL)   \
     do {                                  \

@@ -338,7 +338,7 @@ int tb_order()
 {
     static int v = [] {
         const char* e = getenv("FS_JACOBI_ORDER");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : 0;
     }();
     return v;
 }
