@@ -397,7 +397,6 @@ void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const
     A.p = p - zoff;
     A.np = np - zoff;
     A.div = div - zoff;
-    if (getenv("FS_JACOBI_ABLATE_DIV")) A.div = A.p;   // timing experiment: div loads alias p (results wrong)
     A.nx = g.nx; A.ny = g.ny; A.nz = g.nz;
     A.pitch = g.pitch; A.plane = g.plane;
     A.zin_lo = zin_lo; A.zin_hi = zin_hi;
