@@ -14,11 +14,14 @@
 // value of every level is computed by the very expression above from the previous level, so the
 // result is bit-identical to T separate sweeps; halo cells are recomputed redundantly.
 //
-// Algorithmic traffic stays 12 B per cell per sweep (read p, read div, write p'); the blocked
-// pass moves about (1.4*4 + 1.3*4 + 4) B per cell per T sweeps through HBM.
+// Algorithmic traffic stays 12 B per cell per sweep (read p, read div, write p').  A blocked pass
+// of T = 4 sweeps moves about 18 B per cell through the L2s (measured at 512^3: 1.9 GB of reads,
+// of which the tile halos and the partly used 128-byte lines at the tile edges are ~0.85 GB, and
+// 0.54 GB of writes) and runs at the ~5 TB/s this chip sustains for a 2:1 read/write mix.
 #include "fs_kernels.h"
 
 #include <cstdlib>
+#include <utility>
 
 #pragma clang fp contract(off)
 
@@ -84,24 +87,54 @@ __device__ __forceinline__ bool div6_needs_slow(float q)
     return __builtin_amdgcn_classf(q, 0x001 | 0x002 | 0x004 | 0x200 | 0x010 | 0x080);
 }
 
-// Per-thread registers of the march: for level t, a = plane n-t-2, b = plane n-t-1 and
-// cc = plane n-t of that level; dv[t] = div of plane n-t; q_p / q_d = loads in flight, two
-// march steps deep: slot n & 1 holds p of plane n and div of plane n-1 when step n starts and is
-// refilled by step n with p of plane n+2 and div of plane n+1.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor of plane k of a field: the march addresses memory as (scalar plane base) +
+// (per-lane byte offset that never changes), so a step needs no vector address arithmetic.
+// Offsets at or beyond the plane size are out of range: such a store is dropped by the hardware.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* base, int k, const TbArgs& A)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long)k * A.plane), 0,
+                                             (unsigned)A.plane * 4u, 0x00020000);
+}
+__device__ __forceinline__ f4 plane_load(__amdgpu_buffer_rsrc_t rs, int off)
+{
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+
+constexpr int wrap(int a, int m) { return ((a % m) + m) % m; }
+
+// Per-thread registers of the march.  Every array is indexed by plane number (counted from the
+// workgroup's first step) modulo its ring size, and the march step is compiled once per residue
+// modulo 6, so all indices are compile-time constants and no value ever moves between registers:
+//   q[k % 2]        p of plane k while its load is in flight (planes n+1, n+2 at step n)
+//   w0[k % 3]       p (level 0) of plane k once landed; planes n-2..n
+//   w[t-1][k % 3]   level t (1..T-1) of plane k; planes n-t-2..n-t
+//   dv[k % 6]       div of plane k; planes n-T..n-1 in use, n landed, n+1 in flight
 template <int T, int CPT>
 struct TbRegs {
-    f4 a[T][CPT], b[T][CPT], cc[T][CPT], dv[T + 1][CPT], q_p[2][CPT], q_d[2][CPT];
+    f4 q[2][CPT];
+    f4 w0[3][CPT];
+    f4 w[T > 1 ? T - 1 : 1][3][CPT];
+    f4 dv[6][CPT];
 };
+
+// plane n+OFF of level LV at a step whose residue is PH
+template <int LV, int PH, int OFF, int T, int CPT>
+__device__ __forceinline__ f4& tb_plane(TbRegs<T, CPT>& R, int c)
+{
+    if constexpr (LV == 0) return R.w0[wrap(PH + OFF, 3)][c];
+    else return R.w[LV - 1][wrap(PH + OFF, 3)][c];
+}
 
 // Per-thread constants of the march.
 template <int CPT>
 struct TbLane {
-    int ld_off[CPT];     // clamped into the domain: loads are unconditional and always legal
-    int st_off[CPT];
+    int ld_off[CPT];     // byte offset in a plane, clamped into the domain: loads are always legal
+    int st_off[CPT];     // byte offset in a plane; beyond the plane (store dropped) if not an output
     int row[CPT];        // own LDS row
     int row_dn[CPT];     // LDS row of the y-1 neighbour (own row at the y = 0 wall)
     int row_up[CPT];     // LDS row of the y+1 neighbour (own row at the y = ny-1 wall)
-    bool store[CPT];
     bool at_left, at_right;
     int tx;
 };
@@ -111,97 +144,82 @@ struct TbRange {
     int out_lo, out_hi;  // planes it stores
 };
 
-// One march step.  EDGE = false is the steady state: every level is active, no plane touched
-// is a z wall, the next plane exists and the stored plane is in range, so the body is branch-free
-// apart from the rare slow-division path.
-template <int T, int NTY, int CPT, bool EDGE, int PH>
-__device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L,
-                                        const TbArgs& A, const TbRange& Z, f4* lds)
+// Level t of march step n: produces plane n-t of level t from planes n-t-1, n-t, n-t+1 of
+// level t-1 (registers), the y-neighbours of plane n-t (LDS, written by the previous step) and div.
+// Levels run on every step, also on planes outside the range the workgroup needs (before the
+// ramp-up has reached them, or beyond a z wall): those results are never consumed by a plane that
+// is stored, they keep the register and LDS traffic on one fixed schedule, and the step body is
+// free of branches apart from the uniform wall fix-ups and the rare slow-division path.
+template <int T, int NTY, int CPT, int PH, int t>
+__device__ __forceinline__ void tb_level(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L, const TbArgs& A,
+                                         const TbRange& Z, f4* lcur, const f4* lprv)
 {
-    // PH == n & 1: selects the load slot and the LDS buffer statically
     constexpr int H = NTY * CPT;
-    constexpr int cur = PH, prv = PH ^ 1;
+    const int k = n - t;                                   // plane this level produces now
+    if (k == A.nz - 1) {                                   // clamped z+1 neighbour at the far wall
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) tb_plane<t - 1, PH, -t + 1>(R, c) = tb_plane<t - 1, PH, -t>(R, c);
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const f4 ctr = tb_plane<t - 1, PH, -t>(R, c);      // previous level, plane k
+        const f4 pbo = lprv[((t - 1) * H + L.row_dn[c]) * kW4];   // y - 1
+        const f4 pt = lprv[((t - 1) * H + L.row_up[c]) * kW4];    // y + 1
+        const f4 pbh = tb_plane<t - 1, PH, -t - 1>(R, c);  // z - 1
+        const f4 pf = tb_plane<t - 1, PH, -t + 1>(R, c);   // z + 1
+        float lft = row_prev(ctr.w), rgt = row_next(ctr.x);
+        if (L.at_left) lft = ctr.x;
+        if (L.at_right) rgt = ctr.w;
+        const f4 d = R.dv[wrap(PH - t, 6)][c];
+        const float s0 = lft + ctr.y + pbh.x + pf.x + pbo.x + pt.x - d.x;
+        const float s1 = ctr.x + ctr.z + pbh.y + pf.y + pbo.y + pt.y - d.y;
+        const float s2 = ctr.y + ctr.w + pbh.z + pf.z + pbo.z + pt.z - d.z;
+        const float s3 = ctr.z + rgt + pbh.w + pf.w + pbo.w + pt.w - d.w;
+        f4 r = {div6_fast(s0), div6_fast(s1), div6_fast(s2), div6_fast(s3)};
+        if ((int)div6_needs_slow(r.x) | (int)div6_needs_slow(r.y) | (int)div6_needs_slow(r.z) |
+            (int)div6_needs_slow(r.w)) {
+            r.x = s0 / 6.f;
+            r.y = s1 / 6.f;
+            r.z = s2 / 6.f;
+            r.w = s3 / 6.f;
+        }
+        if constexpr (t < T) {
+            tb_plane<t, PH, -t>(R, c) = r;
+            lcur[(t * H + L.row[c]) * kW4] = r;
+            // plane 0 of level t: its clamped z-1 neighbour, for level t+1 at the next step
+            if (k == 0) tb_plane<t, PH, -t - 1>(R, c) = r;
+        } else if (k >= Z.out_lo && k < Z.out_hi) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), plane_rsrc(A.np, k, A), L.st_off[c], 0, 0);
+        }
+    }
+}
+
+// One march step; PH == (steps since the first one of this workgroup) mod 6.
+template <int T, int NTY, int CPT, int PH, int... Ts>
+__device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L, const TbArgs& A,
+                                        const TbRange& Z, f4* lds, std::integer_sequence<int, Ts...>)
+{
+    constexpr int H = NTY * CPT;
+    constexpr int cur = PH & 1, prv = cur ^ 1;             // LDS buffer written / read by this step
     f4* lcur = lds + cur * (T * H * kW4) + L.tx;
     const f4* lprv = lds + prv * (T * H * kW4) + L.tx;
 
+    // loads run two planes (p) and one plane (div) ahead of their first use; plane numbers are
+    // clamped into the readable range, so every load is legal (and a clamped p plane is exactly
+    // the reference's clamped neighbour at a z wall)
+    const int kp = min(max(n + 2, Z.n_begin), Z.n_end - 1);
+    const int kd = min(max(n + 1, Z.n_begin), Z.n_end - 1);
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        R.cc[0][c] = R.q_p[PH][c];
-        R.dv[1][c] = R.q_d[PH][c];
+        const f4 landed = R.q[PH & 1][c];                  // plane n
+        R.q[PH & 1][c] = plane_load(plane_rsrc(A.p, kp, A), L.ld_off[c]);
+        R.dv[wrap(PH + 1, 6)][c] = plane_load(plane_rsrc(A.div, kd, A), L.ld_off[c]);
+        R.w0[PH % 3][c] = landed;
+        lcur[L.row[c] * kW4] = landed;
+        // plane 0: the clamped z-1 neighbour is the plane itself
+        if (n == 0) R.w0[wrap(PH - 1, 3)][c] = landed;
     }
-    if (!EDGE || n + 2 < Z.n_end) {
-#pragma unroll
-        for (int c = 0; c < CPT; ++c)
-            R.q_p[PH][c] = *reinterpret_cast<const f4*>(A.p + L.ld_off[c] + (n + 2) * A.plane);
-    }
-    if (!EDGE || n + 1 < Z.n_end) {
-#pragma unroll
-        for (int c = 0; c < CPT; ++c)
-            R.q_d[PH][c] = *reinterpret_cast<const f4*>(A.div + L.ld_off[c] + (n + 1) * A.plane);
-    }
-    if (!EDGE || n < Z.n_end) {
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) lcur[L.row[c] * kW4] = R.cc[0][c];
-        if (EDGE && n == 0) {   // plane 0: the clamped z-1 neighbour is the plane itself
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) R.b[0][c] = R.cc[0][c];
-        }
-    }
-#pragma unroll
-    for (int t = 1; t <= T; ++t) {
-        const int k = n - t;                               // plane this level produces now
-        if (EDGE && (k < Z.n_begin || k >= Z.n_end)) continue;   // uniform over the workgroup
-        if (EDGE && k == A.nz - 1) {                       // clamped z+1 neighbour at the far wall
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) R.cc[t - 1][c] = R.b[t - 1][c];
-        }
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            const f4 ctr = R.b[t - 1][c];                  // previous level, plane k
-            const f4 pbo = lprv[((t - 1) * H + L.row_dn[c]) * kW4];   // y - 1
-            const f4 pt = lprv[((t - 1) * H + L.row_up[c]) * kW4];    // y + 1
-            const f4 pbh = R.a[t - 1][c];                  // z - 1
-            const f4 pf = R.cc[t - 1][c];                  // z + 1
-            float lft = row_prev(ctr.w), rgt = row_next(ctr.x);
-            if (L.at_left) lft = ctr.x;
-            if (L.at_right) rgt = ctr.w;
-            const f4 d = R.dv[t][c];
-            const float s0 = lft + ctr.y + pbh.x + pf.x + pbo.x + pt.x - d.x;
-            const float s1 = ctr.x + ctr.z + pbh.y + pf.y + pbo.y + pt.y - d.y;
-            const float s2 = ctr.y + ctr.w + pbh.z + pf.z + pbo.z + pt.z - d.z;
-            const float s3 = ctr.z + rgt + pbh.w + pf.w + pbo.w + pt.w - d.w;
-            f4 r = {div6_fast(s0), div6_fast(s1), div6_fast(s2), div6_fast(s3)};
-            if ((int)div6_needs_slow(r.x) | (int)div6_needs_slow(r.y) | (int)div6_needs_slow(r.z) |
-                (int)div6_needs_slow(r.w)) {
-                r.x = s0 / 6.f;
-                r.y = s1 / 6.f;
-                r.z = s2 / 6.f;
-                r.w = s3 / 6.f;
-            }
-            if (t < T) {
-                R.cc[t][c] = r;
-                lcur[(t * H + L.row[c]) * kW4] = r;
-            } else if (L.store[c] && (!EDGE || (k >= Z.out_lo && k < Z.out_hi))) {
-                *reinterpret_cast<f4*>(A.np + L.st_off[c] + k * A.plane) = r;
-            }
-        }
-        if (EDGE && t < T && k == 0) {   // plane 0 of level t: clamped z-1 neighbour for level t+1
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) R.b[t][c] = R.cc[t][c];
-        }
-    }
-    // slide the windows one plane
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            R.a[t][c] = R.b[t][c];
-            R.b[t][c] = R.cc[t][c];
-        }
-#pragma unroll
-    for (int t = T; t >= 2; --t)
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) R.dv[t][c] = R.dv[t - 1][c];
+    (tb_level<T, NTY, CPT, PH, Ts + 1>(n, R, L, A, Z, lcur, lprv), ...);
     __syncthreads();
 }
 
@@ -224,24 +242,28 @@ k_jacobi_tb(TbArgs A)
     const int rem = lid - bz * (A.tiles_x * A.tiles_y);
     const int by = rem / A.tiles_x;
     const int bx = rem - by * A.tiles_x;
-    const int x = bx * kBX - kHaloX + 4 * L.tx;                  // first cell of the column
-    const bool x_in = x >= 0 && x < A.nx;                        // nx % 4 == 0: all four or none
+    // Tile (bx, by) covers cells [bx*kBX, bx*kBX + 64) x [by*BY, by*BY + H).  Its outer kHaloX
+    // columns and T rows are halo, except where the tile edge is a wall: a wall cell needs nothing
+    // from beyond the wall, so it is an output of the tile like an interior cell.
+    const int x = bx * kBX + 4 * L.tx;                           // first cell of the column
+    const bool x_in = x < A.nx;                                  // nx % 4 == 0: all four or none
     L.at_left = x == 0;
     L.at_right = x + 4 == A.nx;
-    const bool x_out = L.tx >= 1 && L.tx < kW4 - 1;              // column is in the output tile
-    const int xc = min(max(x, 0), A.nx - 4);
+    const bool x_out = (L.tx >= 1 || L.at_left) && (L.tx < kW4 - 1 || L.at_right);
+    const int xc = min(x, A.nx - 4);
+    const int y0 = by * BY;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const int row = ty + c * NTY;
-        const int y = by * BY - T + row;
-        const bool in = x_in && y >= 0 && y < A.ny;
+        const int y = y0 + row;
+        const bool in = x_in && y < A.ny;
         L.row[c] = row;
         // clamped y-neighbours (Solver.cu:435-436): a wall row reads itself
         L.row_dn[c] = (y == 0 || row == 0) ? row : row - 1;
         L.row_up[c] = (y == A.ny - 1 || row == H - 1) ? row : row + 1;
-        L.store[c] = in && x_out && row >= T && row < H - T;
-        L.st_off[c] = x + y * A.pitch;
-        L.ld_off[c] = xc + min(max(y, 0), A.ny - 1) * A.pitch;
+        const bool store = in && x_out && (row >= T || y0 == 0) && (row < H - T || y0 + H >= A.ny);
+        L.st_off[c] = store ? (x + y * A.pitch) * 4 : (int)0xfffffff0u;
+        L.ld_off[c] = (xc + min(y, A.ny - 1) * A.pitch) * 4;
     }
 
     TbRange Z;
@@ -253,46 +275,35 @@ k_jacobi_tb(TbArgs A)
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     TbRegs<T, CPT> R;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int c = 0; c < CPT; ++c) {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) R.a[t][c] = R.b[t][c] = R.cc[t][c] = zero;
+        for (int i = 0; i < 6; ++i) R.dv[i][c] = zero;
+        R.q[0][c] = R.q[1][c] = R.w0[0][c] = R.w0[1][c] = R.w0[2][c] = zero;
 #pragma unroll
-    for (int t = 0; t <= T; ++t)
+        for (int t = 0; t < (T > 1 ? T - 1 : 1); ++t)
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) R.dv[t][c] = zero;
-    // prime the two load slots: p of planes n_begin and n_begin + 1, div of plane n_begin
-    {
-        const int s0 = Z.n_begin & 1;
-        const bool two = Z.n_begin + 1 < Z.n_end;
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            const f4 p0 = *reinterpret_cast<const f4*>(A.p + L.ld_off[c] + Z.n_begin * A.plane);
-            const f4 d0 = *reinterpret_cast<const f4*>(A.div + L.ld_off[c] + Z.n_begin * A.plane);
-            f4 p1 = zero;
-            if (two) p1 = *reinterpret_cast<const f4*>(A.p + L.ld_off[c] + (Z.n_begin + 1) * A.plane);
-            R.q_p[0][c] = s0 ? p1 : p0;
-            R.q_p[1][c] = s0 ? p0 : p1;
-            R.q_d[0][c] = s0 ? d0 : zero;
-            R.q_d[1][c] = s0 ? zero : d0;
-        }
+            for (int i = 0; i < 3; ++i) R.w[t][i][c] = zero;
     }
 
-    // steady range: all levels active (n-T >= n_begin), no z wall among planes n-T..n+2 and
-    // plane n+2 still readable, stored plane n-T inside [out_lo, out_hi)
-    const int steady_lo = max(Z.n_begin + T + 1, Z.out_lo + T);
-    const int steady_hi = min(Z.n_end - 2, Z.out_hi + T);
+    // The march runs from two steps before the first plane (those steps only issue the first
+    // loads) until the last level has drained.  Ring slots are relative to the first step, so
+    // the chain of six step bodies is always entered at its head.
     const int last = Z.n_end + T;
-    int n = Z.n_begin;
-    auto edge_step = [&](int m) {
-        if (m & 1) tb_step<T, NTY, CPT, true, 1>(m, R, L, A, Z, lds);
-        else tb_step<T, NTY, CPT, true, 0>(m, R, L, A, Z, lds);
-    };
-    for (; n < last && (n < steady_lo || (n & 1)); ++n) edge_step(n);
-    for (; n + 1 < steady_hi; n += 2) {
-        tb_step<T, NTY, CPT, false, 0>(n, R, L, A, Z, lds);
-        tb_step<T, NTY, CPT, false, 1>(n + 1, R, L, A, Z, lds);
+    constexpr auto levels = std::make_integer_sequence<int, T>{};
+    for (int n = Z.n_begin - 2;;) {
+        tb_step<T, NTY, CPT, 0>(n, R, L, A, Z, lds, levels);
+        if (++n >= last) break;
+        tb_step<T, NTY, CPT, 1>(n, R, L, A, Z, lds, levels);
+        if (++n >= last) break;
+        tb_step<T, NTY, CPT, 2>(n, R, L, A, Z, lds, levels);
+        if (++n >= last) break;
+        tb_step<T, NTY, CPT, 3>(n, R, L, A, Z, lds, levels);
+        if (++n >= last) break;
+        tb_step<T, NTY, CPT, 4>(n, R, L, A, Z, lds, levels);
+        if (++n >= last) break;
+        tb_step<T, NTY, CPT, 5>(n, R, L, A, Z, lds, levels);
+        if (++n >= last) break;
     }
-    for (; n < last; ++n) edge_step(n);
 }
 
 // plain one-sweep kernel (any nx): one cell per thread
@@ -321,24 +332,27 @@ bool can_block(const FsGrid& g) { return g.nx % 4 == 0 && g.nx >= 8; }
 
 // tile variants: rows of threads (NTY) x columns per thread (CPT); tile rows H = NTY*CPT
 struct TbConfig { int nty, cpt; };
-constexpr TbConfig kConfigs[] = {{40, 1}, {32, 1}, {64, 1}, {36, 2}, {24, 1}, {48, 1}};
+constexpr TbConfig kConfigs[] = {{64, 1}, {32, 1}};
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
-int tb_config()
+// Tile variant for a grid: 64-row tiles (one workgroup of 16 waves per CU) have the smaller halo
+// share and win on large planes; 32-row tiles (two workgroups per CU) give four times as many
+// workgroups per plane and win up to 256^2 (measured 256^3: 1.88 vs 2.15 ms per 80 sweeps,
+// 128^3: 0.26 vs 0.38 ms per 40).  FS_JACOBI_CFG overrides.
+int tb_config(const FsGrid& g)
 {
-    static int cfg = [] {
-        const char* e = getenv("FS_JACOBI_CFG");
-        int v = e ? atoi(e) : 2;
-        return (v >= 0 && v < kNumConfigs) ? v : 2;
-    }();
-    return cfg;
+    if (const char* e = getenv("FS_JACOBI_CFG")) {   // read per launch: tests switch it
+        const int v = atoi(e);
+        if (v >= 0 && v < kNumConfigs) return v;
+    }
+    return (long)g.nx * g.ny >= 384L * 384L ? 0 : 1;
 }
 
 int tb_order()
 {
     static int v = [] {
         const char* e = getenv("FS_JACOBI_ORDER");
-        return e ? atoi(e) : 0;
+        return e ? atoi(e) : 1;
     }();
     return v;
 }
@@ -356,22 +370,29 @@ template <int T, int NTY, int CPT>
 void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
 {
     constexpr int H = NTY * CPT, BY = H - 2 * T;
-    int tiles = cdiv(g.nx, kBX) * cdiv(g.ny, BY);
+    // halo columns / rows at a wall are outputs, so the tiles need to cover n - 2*halo only
+    const int tiles_x = max(1, cdiv(g.nx - 2 * kHaloX, kBX));
+    const int tiles_y = max(1, cdiv(g.ny - 2 * T, BY));
+    int tiles = tiles_x * tiles_y;
     int nout = A.zout_hi - A.zout_lo;
-    // Cut z into chunks so that the workgroups fill whole rounds of the chip.  A workgroup costs
-    // (planes + 2T) march steps (T planes of ramp-up and drain at each chunk edge), and with
-    // `slots` workgroups resident at once the launch takes ceil(blocks / slots) rounds.
+    // Cut z into chunks.  A workgroup costs (planes + 2T + 2) march steps (ramp-up and drain at
+    // each chunk edge).  With `slots` workgroups resident at once, a launch of up to about two
+    // rounds takes ceil(blocks / slots) rounds; with more rounds the workgroups drift apart, the
+    // tail round overlaps the others and the memory system is shared more evenly (measured ~5 %
+    // faster per march step at 512^3), so the cost is the fractional round count.
     constexpr int lds_bytes = 2 * T * H * kW4 * 16;
     constexpr int per_cu_lds = 163840 / lds_bytes;
     constexpr int per_cu_waves = 16 / (kW4 * NTY / 64 > 16 ? 16 : kW4 * NTY / 64);   // <= 4 waves/SIMD at ~128 VGPRs
     const int slots = 256 * max(1, min(per_cu_lds, per_cu_waves));
     int chunks = 1;
-    long best = -1;
+    double best = -1.0;
     for (int c = 1; c <= max(1, nout / 8); ++c) {
-        long rounds = cdiv(tiles * c, slots);
-        long cost = rounds * (cdiv(nout, c) + 2 * T);
-        // a launch that leaves CUs idle in its only round pays for the idle ones too
-        if (tiles * c < slots) cost = cost * slots / (tiles * c);
+        const double r = (double)tiles * c / slots;
+        const double steps = cdiv(nout, c) + 2 * T + 2;
+        double cost;
+        if (r <= 1.0) cost = steps / r;              // idle CUs in the only round are paid for too
+        else if (r < 2.5) cost = cdiv(tiles * c, slots) * steps;
+        else cost = 0.95 * r * steps;
         if (best < 0 || cost < best) {
             best = cost;
             chunks = c;
@@ -380,8 +401,8 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
     A.lz = cdiv(nout, chunks);
     if (tb_chunk_planes() > 0) A.lz = min(nout, tb_chunk_planes());
     chunks = cdiv(nout, A.lz);
-    A.tiles_x = cdiv(g.nx, kBX);
-    A.tiles_y = cdiv(g.ny, BY);
+    A.tiles_x = tiles_x;
+    A.tiles_y = tiles_y;
     A.nblocks = A.tiles_x * A.tiles_y * chunks;
     A.order = tb_order();
     dim3 grid(A.nblocks), block(kW4, NTY);
@@ -402,13 +423,9 @@ void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const
     A.zin_lo = zin_lo; A.zin_hi = zin_hi;
     A.zout_lo = zout_lo; A.zout_hi = zout_hi;
     A.lz = 0;
-    switch (tb_config()) {
+    switch (tb_config(g)) {
     case 1: launch_tb_cfg<T, 32, 1>(st, g, A); break;
-    case 2: launch_tb_cfg<T, 64, 1>(st, g, A); break;
-    case 3: launch_tb_cfg<T, 36, 2>(st, g, A); break;
-    case 4: launch_tb_cfg<T, 24, 1>(st, g, A); break;
-    case 5: launch_tb_cfg<T, 48, 1>(st, g, A); break;
-    default: launch_tb_cfg<T, 40, 1>(st, g, A); break;
+    default: launch_tb_cfg<T, 64, 1>(st, g, A); break;
     }
 }
 

@@ -470,7 +470,10 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     g.ghost = ghost;
     g.wall_lo = rank == 0;
     g.wall_hi = rank == world - 1;
+    // an odd multiple of 16 floats: consecutive rows start in alternate halves of a 128-byte
+    // line, which measures ~8 % faster on the stencil kernels than line-aligned rows
     g.pitch = round_up(p->nx + 3, 16);
+    if (g.pitch % 32 == 0) g.pitch += 16;
     long long plane = (long long)g.pitch * (p->ny + 3);
     long long planes = (long long)g.nzl + 1 + 2 * g.ghost;
     // kernels index with 32-bit element offsets relative to global plane 0

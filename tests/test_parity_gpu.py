@@ -94,6 +94,27 @@ def test_jacobi_random(fs, oracle, dims, sweeps):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("dims", [(132, 70, 23), (64, 61, 9), (60, 124, 40), (8, 1, 5), (196, 130, 12)])
+def test_jacobi_tile_variants(fs, oracle, dims, cfg, monkeypatch):
+    """Both tile shapes of the blocked kernel (64- and 32-row tiles) on grids with several tiles
+    per direction, tile edges that coincide with walls, walls in mid-tile and single-tile grids;
+    8 and 6 sweeps (two fused passes; a fused pass plus two single sweeps)."""
+    monkeypatch.setenv("FS_JACOBI_CFG", str(cfg))
+    nx, ny, nz = dims
+    for sweeps in (8, 6):
+        g, o = make_pair(fs, oracle, nx, ny, nz, jacobi_iters=sweeps)
+        st = random_fields(nx, ny, nz, seed=31 + sweeps + cfg)
+        load_state(g, o, st)
+        g.stage("jacobi", sweeps)
+        p, div = st[5], st[6]
+        for _ in range(sweeps):
+            p, _r = oracle.jacobi(p, div, want_r=False)
+        got = g.field(fs.FS_P)
+        assert np.array_equal(got, p), "cfg %d dims %s: %d mismatches" % (cfg, dims, int((got != p).sum()))
+        g.close(); o.close()
+
+
 @pytest.mark.parametrize("scheme", [0, 1])
 @pytest.mark.parametrize("dims", [(24, 20, 18), (33, 9, 14)])
 def test_advect_smooth_and_rough(fs, oracle, dims, scheme):

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_ranks(world, args, port):
+def run_ranks(world, args, port, env_extra=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "slab_worker.py")] + [str(a) for a in args]
-    env = dict(os.environ, OMP_NUM_THREADS="4")
+    env = dict(os.environ, OMP_NUM_THREADS="4", **(env_extra or {}))
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=280, text=True)
     assert r.returncode == 0 and "SLAB_OK" in r.stdout, r.stdout[-3000:]
@@ -34,6 +34,12 @@ def run_ranks(world, args, port):
 ])
 def test_slab_matches_oracle(world, dims, steps, k, extra):
     run_ranks(world, ["host", *dims, steps, k, *extra], 29611 + world)
+
+
+def test_slab_tall_tiles_multi_tile():
+    """64-row Jacobi tiles (the large-grid variant) with several tiles per plane, 7 sweeps: the slab
+    passes of 4 and 3 sweeps read 4 / 3 ghost planes and recompute the intermediate ones."""
+    run_ranks(2, ["host", 72, 68, 24, 3, 7], 29621, {"FS_JACOBI_CFG": "0"})
 
 
 def test_slab_convergence_mode():
