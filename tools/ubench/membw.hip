@@ -28,9 +28,12 @@ __global__ void k_mix21(const f4* __restrict__ a, const f4* __restrict__ c, f4* 
     }
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-int main()
+int main(int argc, char** argv)
 {
-    size_t bytes = (size_t)1 << 30, n = bytes / 16;
+    size_t mib = argc > 1 ? atoi(argv[1]) : 1024;
+    size_t bytes = mib << 20, n = bytes / 16;
+    const double gib = bytes / 1e9;   // GB per buffer
+    printf("buffers of %zu MiB\n", mib);
     f4 *a, *b, *c;
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&c, bytes));
     CK(hipMemset(a, 0, bytes)); CK(hipMemset(b, 0, bytes)); CK(hipMemset(c, 0, bytes));
@@ -42,13 +45,13 @@ int main()
         for (int i = 0; i < 10; ++i) launch();
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("%-28s %7.1f us  %6.2f TB/s\n", name, ms * 100, gb * 10 / ms);
+        printf("%-28s %7.1f us  %6.2f TB/s\n", name, ms * 100, gb * 10 / ms / 1e3 * 1e3);
     };
-    timeit("read 1 GiB", 1.0737, [&] { hipLaunchKernelGGL(k_read, grid, block, 0, 0, a, b, n); });
-    timeit("write 1 GiB", 1.0737, [&] { hipLaunchKernelGGL(k_write, grid, block, 0, 0, b, n, 0); });
-    timeit("write 1 GiB, 224/256 B rows", 1.0737 * 14 / 16, [&] { hipLaunchKernelGGL(k_write, grid, block, 0, 0, b, n, 1); });
-    timeit("copy 1+1 GiB", 2 * 1.0737, [&] { hipLaunchKernelGGL(k_copy, grid, block, 0, 0, a, b, n); });
-    timeit("mix 2 reads + 1 write", 3 * 1.0737, [&] { hipLaunchKernelGGL(k_mix21, grid, block, 0, 0, a, c, b, n, 0); });
-    timeit("mix 2r + 1w, 224/256 rows", (2 + 14. / 16) * 1.0737, [&] { hipLaunchKernelGGL(k_mix21, grid, block, 0, 0, a, c, b, n, 1); });
+    timeit("read", gib, [&] { hipLaunchKernelGGL(k_read, grid, block, 0, 0, a, b, n); });
+    timeit("write", gib, [&] { hipLaunchKernelGGL(k_write, grid, block, 0, 0, b, n, 0); });
+    timeit("write, 224/256 B rows", gib * 14 / 16, [&] { hipLaunchKernelGGL(k_write, grid, block, 0, 0, b, n, 1); });
+    timeit("copy 1 read + 1 write", 2 * gib, [&] { hipLaunchKernelGGL(k_copy, grid, block, 0, 0, a, b, n); });
+    timeit("mix 2 reads + 1 write", 3 * gib, [&] { hipLaunchKernelGGL(k_mix21, grid, block, 0, 0, a, c, b, n, 0); });
+    timeit("mix 2r + 1w, 224/256 rows", (2 + 14. / 16) * gib, [&] { hipLaunchKernelGGL(k_mix21, grid, block, 0, 0, a, c, b, n, 1); });
     return 0;
 }
