@@ -54,6 +54,8 @@ struct TbArgs {
     int pitch, plane;
     int zin_lo, zin_hi;  // level-0 planes that may be read: [zin_lo, zin_hi)
     int zout_lo, zout_hi;// planes to produce
+    int zout2_lo, zout2_hi;  // optional second range of planes to produce (empty if lo >= hi)
+    int chunks1;         // z chunks of the first range; chunks beyond it belong to the second
     int lz;              // output planes per workgroup along z
     int tiles_x, tiles_y, nblocks;
     int order;           // 0: plain block order, 1: XCD-contiguous (z-chunk, y, x) order
@@ -267,8 +269,9 @@ k_jacobi_tb(TbArgs A)
     }
 
     TbRange Z;
-    Z.out_lo = A.zout_lo + bz * A.lz;
-    Z.out_hi = min(Z.out_lo + A.lz, A.zout_hi);
+    const bool second = bz >= A.chunks1;
+    Z.out_lo = second ? A.zout2_lo + (bz - A.chunks1) * A.lz : A.zout_lo + bz * A.lz;
+    Z.out_hi = min(Z.out_lo + A.lz, second ? A.zout2_hi : A.zout_hi);
     Z.n_begin = max(Z.out_lo - T, A.zin_lo);
     Z.n_end = min(Z.out_hi + T, A.zin_hi);
 
@@ -374,7 +377,8 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
     const int tiles_x = max(1, cdiv(g.nx - 2 * kHaloX, kBX));
     const int tiles_y = max(1, cdiv(g.ny - 2 * T, BY));
     int tiles = tiles_x * tiles_y;
-    int nout = A.zout_hi - A.zout_lo;
+    const int n1 = A.zout_hi - A.zout_lo, n2 = max(0, A.zout2_hi - A.zout2_lo);
+    int nout = n1 + n2;
     // Cut z into chunks.  A workgroup costs (planes + 2T + 2) march steps (ramp-up and drain at
     // each chunk edge).  With `slots` workgroups resident at once, a launch of up to about two
     // rounds takes ceil(blocks / slots) rounds; with more rounds the workgroups drift apart, the
@@ -400,7 +404,8 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
     }
     A.lz = cdiv(nout, chunks);
     if (tb_chunk_planes() > 0) A.lz = min(nout, tb_chunk_planes());
-    chunks = cdiv(nout, A.lz);
+    A.chunks1 = cdiv(n1, A.lz);      // chunks never straddle the two ranges
+    chunks = A.chunks1 + cdiv(n2, A.lz);
     A.tiles_x = tiles_x;
     A.tiles_y = tiles_y;
     A.nblocks = A.tiles_x * A.tiles_y * chunks;
@@ -411,7 +416,7 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
 
 template <int T>
 void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
-               int zin_lo, int zin_hi, int zout_lo, int zout_hi)
+               int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo = 0, int zout2_hi = 0)
 {
     TbArgs A;
     ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
@@ -422,6 +427,8 @@ void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const
     A.pitch = g.pitch; A.plane = g.plane;
     A.zin_lo = zin_lo; A.zin_hi = zin_hi;
     A.zout_lo = zout_lo; A.zout_hi = zout_hi;
+    A.zout2_lo = zout2_lo; A.zout2_hi = zout2_hi;
+    A.chunks1 = 0;
     A.lz = 0;
     switch (tb_config(g)) {
     case 1: launch_tb_cfg<T, 32, 1>(st, g, A); break;
@@ -445,16 +452,22 @@ void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, co
 
 int jacobi_block() { return kT; }
 
+bool jacobi_can_block(const FsGrid& g) { return can_block(g); }
+
 bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
-                 int sweeps, int zin_lo, int zin_hi, int zout_lo, int zout_hi)
+                 int sweeps, int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo, int zout2_hi)
 {
     if (!can_block(g) || sweeps < 1 || sweeps > kT) return false;
+    if (zout_hi <= zout_lo) {   // only the second range, or nothing
+        zout_lo = zout2_lo; zout_hi = zout2_hi;
+        zout2_lo = zout2_hi = 0;
+    }
     if (zout_hi <= zout_lo) return true;
     switch (sweeps) {
-    case 1: launch_tb<1>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi); break;
-    case 2: launch_tb<2>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi); break;
-    case 3: launch_tb<3>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi); break;
-    default: launch_tb<4>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi); break;
+    case 1: launch_tb<1>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi, zout2_lo, zout2_hi); break;
+    case 2: launch_tb<2>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi, zout2_lo, zout2_hi); break;
+    case 3: launch_tb<3>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi, zout2_lo, zout2_hi); break;
+    default: launch_tb<4>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi, zout2_lo, zout2_hi); break;
     }
     return true;
 }

@@ -62,9 +62,13 @@ void jacobi_multi(hipStream_t st, const FsGrid& g, float* p, float* np, const fl
 // One pass of `sweeps` (1..jacobi_block()) fused sweeps p -> np: level-0 planes [zin_lo, zin_hi)
 // are read (ghost planes included), planes [zout_lo, zout_hi) are written.  A plane range edge
 // that is not a global wall loses one plane of validity per sweep, so zout must lie `sweeps`
-// planes inside zin there.  Returns false if this grid cannot take the fused kernel.
+// planes inside zin there.  [zout2_lo, zout2_hi) is an optional second range produced by the same
+// launch (the two boundary layers of a slab).  Returns false if this grid cannot take the fused
+// kernel.
 bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
-                 int sweeps, int zin_lo, int zin_hi, int zout_lo, int zout_hi);
+                 int sweeps, int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo = 0,
+                 int zout2_hi = 0);
+bool jacobi_can_block(const FsGrid& g);
 int jacobi_block();   // sweeps fused per pass
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
 int jacobi_launches(const FsGrid& g, int sweeps, int naive);

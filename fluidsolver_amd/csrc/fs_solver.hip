@@ -10,8 +10,10 @@
 // neighbours from identical inputs, so results are bit-identical to one GPU.  Every array
 // carries `ghost` planes on each z side.  Ghost planes are refreshed lazily, only when a stage
 // needs them: old velocity + T + rho before the velocity advection, the new velocity before the
-// scalar advection, jacobi_block() planes of p before each fused Jacobi pass (one exchange per
-// 4 sweeps), one plane of p before the gradient.  Planes are contiguous in memory, so a halo is
+// scalar advection.  A fused Jacobi pass first produces the jacobi_block() planes next to each
+// neighbour, sends them (one exchange per 4 sweeps) and produces the slab interior while they
+// travel; the gradient then finds the ghost planes of p already valid.  Planes are contiguous in
+// memory, so a halo is
 // one send and one receive per field and neighbour, straight from and into the arrays, with
 // RCCL (ncclSend/ncclRecv in one group, on a communication stream ordered against the compute
 // stream by events).  The only collective is the all-reduce of the residual norm.
@@ -146,6 +148,7 @@ struct fs_solver {
     size_t h_stage_cap = 0;
     bool vel_ghost_ok = false, scal_ghost_ok = false;
     int p_ghost = 0;                  // valid ghost planes of p on each side
+    bool halo_pending = false;        // an exchange is in flight; exchange_wait() orders the compute stream after it
     // stage timing with HIP events on the solver's own stream (fs_profile_*)
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
@@ -236,9 +239,23 @@ Seg make_seg(const fs_solver* s, float* base, int n, bool face)
     return g;
 }
 
-int exchange(fs_solver* s, const Seg* segs, int nseg)
+// Compute-stream work enqueued after exchange_begin() runs concurrently with the transfer (RCCL
+// transport) until exchange_wait() makes the compute stream wait for the received planes.
+int exchange_wait(fs_solver* s)
+{
+    if (!s->halo_pending) return FS_OK;
+    s->halo_pending = false;
+    FS_HIP(hipStreamWaitEvent(s->st, s->ev_done, 0));
+    return FS_OK;
+}
+
+int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
 {
     if (s->world == 1 || nseg == 0) return FS_OK;
+    {
+        int rc = exchange_wait(s);   // one exchange in flight at a time
+        if (rc) return rc;
+    }
     const bool lo = !s->g.wall_lo, hi = !s->g.wall_hi;
     if (s->comm) {
         Rccl* R = rccl();
@@ -258,9 +275,9 @@ int exchange(fs_solver* s, const Seg* segs, int nseg)
             }
         }
         FS_NCCL(R->GroupEnd());
-        // ... and the consumers on the compute stream wait for the halos
+        // ... and the consumers on the compute stream wait for the halos in exchange_wait()
         FS_HIP(hipEventRecord(s->ev_done, s->cs));
-        FS_HIP(hipStreamWaitEvent(s->st, s->ev_done, 0));
+        s->halo_pending = true;
         return FS_OK;
     }
     // host-staged transport: pack through pinned buffers, let the caller's function move them
@@ -293,6 +310,12 @@ int exchange(fs_solver* s, const Seg* segs, int nseg)
         off += nb;
     }
     return FS_OK;
+}
+
+int exchange(fs_solver* s, const Seg* segs, int nseg)
+{
+    int rc = exchange_begin(s, segs, nseg);
+    return rc ? rc : exchange_wait(s);
 }
 
 int ensure_velocity_ghosts(fs_solver* s)
@@ -336,7 +359,8 @@ int ensure_advect_ghosts(fs_solver* s)
 
 int ensure_p_ghosts(fs_solver* s, int planes)
 {
-    if (s->world == 1 || s->p_ghost >= planes) return FS_OK;
+    if (s->world == 1) return FS_OK;
+    if (s->p_ghost >= planes) return exchange_wait(s);
     Seg seg = make_seg(s, s->f.p, planes, false);
     int rc = exchange(s, &seg, 1);
     if (rc == FS_OK) s->p_ghost = planes;
@@ -359,11 +383,16 @@ int run_jacobi(fs_solver* s, int sweeps)
         s->prev_held = held != 0;
         if (in_np) std::swap(s->f.p, s->f.np);
     } else {
-        // slab: refresh t ghost planes of p, then t fused sweeps over the owned planes; a slab
-        // face that is not a global wall loses one plane of validity per sweep, which is what the
-        // t ghost planes pay for
+        // slab: t fused sweeps need t valid ghost planes of p; a slab face that is not a global
+        // wall loses one plane of validity per sweep, which is what the ghost planes pay for.
+        // Each fused pass runs as two launches: first the T boundary planes next to each neighbour,
+        // whose results then travel to the neighbours' ghost planes while the second launch
+        // produces the interior, which needs no ghost plane.  So every pass has exactly one
+        // exchange, hidden behind its interior, and the pressure leaves the solve with T valid
+        // ghost planes (what the gradient and the next step's first pass need).
         const int T = naive ? 1 : fsk::jacobi_block();
         const int z1 = g.z0 + g.nzl;
+        const bool split = !naive && fsk::jacobi_can_block(g) && g.nzl >= 2 * T + 1;
         int left = sweeps, launches = 0;
         StageScope sc(s, FS_STAGE_JACOBI, 0);
         while (left > 0) {
@@ -371,17 +400,34 @@ int run_jacobi(fs_solver* s, int sweeps)
             int rc = ensure_p_ghosts(s, t);
             if (rc) return rc;
             const int zin_lo = g.wall_lo ? 0 : g.z0 - t, zin_hi = g.wall_hi ? g.nz : z1 + t;
-            bool fused = !naive && fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo,
-                                                    zin_hi, g.z0, z1);
-            if (!fused) {
-                t = 1;
-                fsk::jacobi_sweep(s->st, g, s->f.p, s->f.np, s->f.div, g.z0, z1);
+            if (split) {
+                // boundary layers [z0, z0+T) and [z1-T, z1) (none at a global wall), then interior
+                const int ilo = g.wall_lo ? g.z0 : g.z0 + T, ihi = g.wall_hi ? z1 : z1 - T;
+                fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, g.z0, ilo, ihi, z1);
+                Seg seg = make_seg(s, s->f.np, T, false);
+                rc = exchange_begin(s, &seg, 1);
+                if (rc) return rc;
+                fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, ilo, ihi);
+                std::swap(s->f.p, s->f.np);
+                s->p_ghost = T;
+                launches += 2;
+            } else {
+                bool fused = !naive && fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo,
+                                                        zin_hi, g.z0, z1);
+                if (!fused) {
+                    t = 1;
+                    fsk::jacobi_sweep(s->st, g, s->f.p, s->f.np, s->f.div, g.z0, z1);
+                }
+                std::swap(s->f.p, s->f.np);
+                s->p_ghost = 0;
+                ++launches;
             }
-            std::swap(s->f.p, s->f.np);
-            s->p_ghost = 0;
             s->prev_held = t == 1;
             left -= t;
-            ++launches;
+        }
+        {
+            int rc = exchange_wait(s);
+            if (rc) return rc;
         }
         if (s->profiling) s->prof_launches[FS_STAGE_JACOBI] += launches;
     }
@@ -528,7 +574,11 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             fsk::fill_interior(s->st, all, s->f.T - (ptrdiff_t)lo * g.plane, p->temperature_env);
         }
         if (world > 1) {
-            if (hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess ||
+            // the halo transfers are short and sit on the critical path of the next pass: give
+            // their stream the highest priority so they are not queued behind the interior kernels
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            if (hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, prio_hi) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming) != hipSuccess) {
                 rc = fail(FS_ERR_HIP, "fs_create_slab: stream/event creation failed");

@@ -3,7 +3,7 @@
 No GPU here, so the HIP kernels cannot run; what these tests pin is the decomposition itself --
 which ghost planes are refreshed when, and how wide -- by replaying the library's orchestration
 (fluidsolver_amd/csrc/fs_solver.hip: ensure_advect_ghosts / ensure_velocity_ghosts /
-ensure_p_ghosts, extended divergence range, 4-sweep Jacobi passes on 4 ghost planes) with the CPU
+run_jacobi's split passes with one exchange of 4 planes after each, extended divergence range) with the CPU
 oracle's kernels.  Every rank keeps full-size arrays but only its owned + ghost planes hold data;
 everything else is poisoned with NaN after each exchange, so any read beyond the ghost planes,
 and any stale ghost, shows up as a mismatch against the single-domain oracle.  The same file
@@ -101,6 +101,7 @@ def _slab_worker(rank, world, port, dims, steps, k, result):
                 _poison(a, z0, z1, f, rank, world)
 
         ok = True
+        p_ghost = GHOST      # all-zero initial pressure: the ghost planes are valid
         for step in range(steps):
             ref.step()
             oracle.source(rho, T, par.source_x, par.source_y, par.source_z, par.source_radius, par.rho0, par.temperature0)
@@ -120,15 +121,19 @@ def _slab_worker(rank, world, port, dims, steps, k, result):
             left = k
             while left > 0:
                 t = min(BLOCK, left)
-                refresh([p], t, [False])                                                 # ensure_p_ghosts(t)
+                if p_ghost < t:
+                    refresh([p], t, [False])                                             # ensure_p_ghosts(t)
                 plo = 0 if rank == 0 else z0 - t
                 phi = nz if rank == world - 1 else z1 + t
                 q = p.copy(); q[:plo] = np.nan; q[phi:] = np.nan
                 for _ in range(t):
                     q, _r = oracle.jacobi(q, div, want_r=False)
                 p = own(p, q)
+                # the boundary layers of the new iterate travel while the interior is computed
+                refresh([p], BLOCK, [False])
+                p_ghost = BLOCK
                 left -= t
-            refresh([p], 1, [False])                                                     # ensure_p_ghosts(1)
+            assert p_ghost >= 1                                                          # ensure_p_ghosts(1): nothing to do
             gx, gy, gz = ux.copy(), uy.copy(), uz.copy()
             oracle.gradient(gx, gy, gz, p)
             ux, uy, uz = own(ux, gx), own(uy, gy), own(uz, gz, face=True)
