@@ -1,6 +1,7 @@
 // fs_bench.cpp -- headless C++ benchmark over the C ABI only (no Python, no torch).
 //   fs_bench [n=256] [sweeps=80] [steps=20] [warmup=5] [dump_prefix]
-// Prints one JSON line: cell-updates/s and per-stage device time.  With dump_prefix, writes
+// Prints one JSON line: cell-updates/s of `steps` steps and, from a second profiled run of as
+// many steps, the device time per stage.  With dump_prefix, writes
 // the final rho/ux/uy/uz as raw little-endian float32, x fastest (dense reference layout).
 #include "fluidsolver.h"
 
@@ -29,11 +30,14 @@ int main(int argc, char** argv)
 	fs_solver* s = nullptr;
 	if (fs_create(&p, &s)) die("fs_create");
 	if (fs_steps(s, warmup) || fs_sync(s)) die("warmup");
-	fs_profile_enable(s, 1);
-	fs_profile_reset(s);
+	// pass 1: the product path (graph replay), wall clock around `steps` steps
 	auto t0 = std::chrono::steady_clock::now();
 	if (fs_steps(s, steps) || fs_sync(s)) die("fs_steps");
 	double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	// pass 2: the same steps launched eagerly with a pair of events around every stage
+	fs_profile_enable(s, 1);
+	fs_profile_reset(s);
+	if (fs_steps(s, steps) || fs_sync(s)) die("fs_steps (profiled)");
 	static const char* names[FS_NUM_STAGES] = {"source", "force", "advect_velocity", "advect_scalars",
 	                                           "divergence", "jacobi", "gradient"};
 	std::printf("{\"n\": %d, \"sweeps\": %d, \"steps\": %d, \"ms_per_step\": %.4f, \"cell_updates_per_s\": %.6e, "

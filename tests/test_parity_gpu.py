@@ -216,3 +216,33 @@ def test_convergence_mode(fs, oracle):
         o.stage("gradient")
         assert_all_equal(g, o, what="convergence mode")
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("k", [8, 6, 5])
+def test_graph_replay_matches_eager_launches(fs, oracle, k):
+    """fs_step replays a captured graph per buffer assignment; FS_FLAG_NO_GRAPH launches eagerly.
+    Both must give the same bits as the oracle, also when stage calls and uploads between steps
+    change which buffer plays which role (k = 6 and 5 leave the pressure in the other buffer
+    after a step, so consecutive steps alternate between assignments)."""
+    nx, ny, nz = 24, 28, 20
+    kw = dict(jacobi_iters=k, source_y=8.0, source_radius=5.0)
+    g, o = make_pair(fs, oracle, nx, ny, nz, **kw)
+    e, _o2 = make_pair(fs, oracle, nx, ny, nz, flags=fs.FS_FLAG_NO_GRAPH, **kw)
+    _o2.close()
+    for rnd in range(3):
+        for _ in range(3):
+            g.step(); e.step(); o.step()
+        assert_all_equal(g, o, what="graph k=%d round %d" % (k, rnd))
+        assert_all_equal(e, o, what="eager k=%d round %d" % (k, rnd))
+        # break the period: one stage call that swaps buffers, and an upload
+        for s in (g, e):
+            s.stage("source"); s.stage("force"); s.stage("advect")
+        o.stage("source"); o.stage("force"); o.stage("advect")
+        st = random_fields(nx, ny, nz, seed=90 + rnd)
+        for s in (g, e):
+            s.upload(fs.FS_P, st[5])
+        o.set(5, st[5])
+    g.step(2); e.step(2); o.step(); o.step()
+    assert_all_equal(g, o, what="graph k=%d final" % k)
+    assert_all_equal(e, o, what="eager k=%d final" % k)
+    g.close(); e.close(); o.close()
