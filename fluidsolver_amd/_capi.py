@@ -13,20 +13,23 @@ FIELD_NAMES = {FS_UX: "ux", FS_UY: "uy", FS_UZ: "uz", FS_RHO: "rho", FS_T: "T", 
 FS_SCHEME_RK4, FS_SCHEME_MACCORMACK = 0, 1
 FS_FLAG_NO_GRAPH = 1 << 0
 FS_FLAG_JACOBI_NAIVE = 1 << 1
+FS_FLAG_VORT_CONFINE = 1 << 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # every symbol include/fluidsolver.h declares
 EXPORTED_SYMBOLS = (
     "fs_default_params", "fs_create", "fs_destroy", "fs_step", "fs_steps", "fs_sync", "fs_frame",
-    "fs_stage_source", "fs_stage_force", "fs_stage_advect", "fs_stage_divergence",
+    "fs_stage_source", "fs_stage_force", "fs_stage_vorticity", "fs_stage_advect", "fs_stage_confine",
+    "fs_stage_divergence",
     "fs_stage_jacobi", "fs_stage_project", "fs_stage_gradient", "fs_density_host",
     "fs_velocity_host", "fs_field_host", "fs_field_size", "fs_field_upload", "fs_field_device",
     "fs_residual", "fs_last_sweeps", "fs_last_error", "fs_version",
     "fs_profile_enable", "fs_profile_read", "fs_profile_reset",
 )
 
-STAGES = ("source", "force", "advect_velocity", "advect_scalars", "divergence", "jacobi", "gradient")
+STAGES = ("source", "force", "advect_velocity", "advect_scalars", "divergence", "jacobi", "gradient",
+          "vorticity", "confine")
 
 
 class FsError(RuntimeError):
@@ -51,6 +54,7 @@ class Params(C.Structure):
         ("tolerance", C.c_float),
         ("check_every", C.c_int),
         ("max_sweeps", C.c_int),
+        ("curl_strength", C.c_float),
     ]
 
 
@@ -87,7 +91,7 @@ def load_library():
     L.fs_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     for name in ("fs_destroy", "fs_step", "fs_sync", "fs_frame", "fs_stage_source", "fs_stage_force",
                  "fs_stage_advect", "fs_stage_divergence", "fs_stage_project", "fs_stage_gradient",
-                 "fs_last_sweeps"):
+                 "fs_stage_vorticity", "fs_stage_confine", "fs_last_sweeps"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = C.c_int
     L.fs_steps.argtypes = [vp, C.c_int]

@@ -390,7 +390,8 @@ __device__ __forceinline__ void stage_velocity(float* lds, const Vel& v, int ox,
 // ---- back-trace ----------------------------------------------------------------------------
 
 // Solver.cu:139-161.  (0.5f*dt) is formed first, then scales each component
-// (Math.cuh:80-86); the final update is  pos - (dt * sum) / 6  with a true division.
+// (Math.cuh:80-86); the final update is  pos - (dt * sum) / 6  with a true division (fsk::div6
+// returns the same correctly rounded quotient).
 template <bool HALO, class S>
 __device__ __forceinline__ float3 rk4(const S& s, float3 pos, float dt, int& bad, const float3* first)
 {
@@ -405,8 +406,7 @@ __device__ __forceinline__ float3 rk4(const S& s, float3 pos, float dt, int& bad
     float sx = ((u1.x + 2.0f * u2.x) + 2.0f * u3.x) + u4.x;
     float sy = ((u1.y + 2.0f * u2.y) + 2.0f * u3.y) + u4.y;
     float sz = ((u1.z + 2.0f * u2.z) + 2.0f * u3.z) + u4.z;
-    return make_float3(pos.x - (dt * sx) / 6.0f, pos.y - (dt * sy) / 6.0f,
-                       pos.z - (dt * sz) / 6.0f);
+    return make_float3(pos.x - fsk::div6(dt * sx), pos.y - fsk::div6(dt * sy), pos.z - fsk::div6(dt * sz));
 }
 
 // Solver.cu:163-169 (MAC) or the plain RK4 trace of Solver.cu:396.

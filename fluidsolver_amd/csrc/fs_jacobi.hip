@@ -71,24 +71,6 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-// x / 6 rounded to nearest, bit-identical to the IEEE division for every finite x whose
-// quotient is a normal number: q = RN(x*c) with c = RN(1/6) is within one ulp of x/6, the
-// remainder r = x - 6q is exact in an FMA, and RN(q + r*c) is then the correctly rounded
-// quotient (x/6 is never within 2^-25 ulp of a rounding boundary because 6 = 2*3).  Zero,
-// subnormal, infinite and NaN quotients take the true division.
-__device__ __forceinline__ float div6_fast(float x)
-{
-    const float c = 0x1.555556p-3f;   // RN(1/6)
-    float q = x * c;
-    float r = __builtin_fmaf(-6.0f, q, x);
-    return __builtin_fmaf(r, c, q);
-}
-// classes of q that div6_fast does not cover: NaNs, infinities, subnormals
-__device__ __forceinline__ bool div6_needs_slow(float q)
-{
-    return __builtin_amdgcn_classf(q, 0x001 | 0x002 | 0x004 | 0x200 | 0x010 | 0x080);
-}
-
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 // Buffer descriptor of plane k of a field: the march addresses memory as (scalar plane base) +
@@ -151,7 +133,7 @@ struct TbRange {
 // Levels run on every step, also on planes outside the range the workgroup needs (before the
 // ramp-up has reached them, or beyond a z wall): those results are never consumed by a plane that
 // is stored, they keep the register and LDS traffic on one fixed schedule, and the step body is
-// free of branches apart from the uniform wall fix-ups and the rare slow-division path.
+// free of branches apart from the uniform wall fix-ups.
 template <int T, int NTY, int CPT, int PH, int t>
 __device__ __forceinline__ void tb_level(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L, const TbArgs& A,
                                          const TbRange& Z, f4* lcur, const f4* lprv)
@@ -177,14 +159,7 @@ __device__ __forceinline__ void tb_level(int n, TbRegs<T, CPT>& R, const TbLane<
         const float s1 = ctr.x + ctr.z + pbh.y + pf.y + pbo.y + pt.y - d.y;
         const float s2 = ctr.y + ctr.w + pbh.z + pf.z + pbo.z + pt.z - d.z;
         const float s3 = ctr.z + rgt + pbh.w + pf.w + pbo.w + pt.w - d.w;
-        f4 r = {div6_fast(s0), div6_fast(s1), div6_fast(s2), div6_fast(s3)};
-        if ((int)div6_needs_slow(r.x) | (int)div6_needs_slow(r.y) | (int)div6_needs_slow(r.z) |
-            (int)div6_needs_slow(r.w)) {
-            r.x = s0 / 6.f;
-            r.y = s1 / 6.f;
-            r.z = s2 / 6.f;
-            r.w = s3 / 6.f;
-        }
+        const f4 r = {fsk::div6(s0), fsk::div6(s1), fsk::div6(s2), fsk::div6(s3)};
         if constexpr (t < T) {
             tb_plane<t, PH, -t>(R, c) = r;
             lcur[(t * H + L.row[c]) * kW4] = r;

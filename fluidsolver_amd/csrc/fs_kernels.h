@@ -35,6 +35,21 @@ struct FsSource {
 
 namespace fsk {
 
+#if defined(__HIPCC__)
+// x / 6.f, correctly rounded for every binary32 x (what the true division of the reference yields,
+// Solver.cu:160, 441), as RN32(RN64(x * RN64(1/6))): three instructions instead of the ten of the
+// IEEE division sequence.  Why the two roundings cannot disagree with the one of the exact
+// quotient: the product is within 2^-52 (relative) of x/6; x/6 with a 24-bit x is either exactly
+// a binary32 rounding boundary -- only possible for a subnormal quotient, and then the product
+// rounds to that boundary itself, so the narrowing conversion breaks the same tie to even -- or at
+// least 2^-27 (relative) away from every boundary, because 6 * boundary has an odd factor that x
+// cannot match.  Zeros keep their sign, infinities and NaNs pass through.
+__device__ __forceinline__ float div6(float x)
+{
+    return (float)((double)x * 0x1.5555555555555p-3);
+}
+#endif
+
 void fill_interior(hipStream_t st, const FsGrid& g, float* f, float value);
 void source(hipStream_t st, const FsGrid& g, const FsSource& src, float* rho, float* T);
 void force_uy(hipStream_t st, const FsGrid& g, float* uy, const float* T, float dt, float T_env);
@@ -73,6 +88,13 @@ int jacobi_block();   // sweeps fused per pass
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
 int jacobi_launches(const FsGrid& g, int sweeps, int naive);
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p);
+// Vorticity confinement (single slab only).  The three vorticity arrays are dense, vort_elems(g)
+// floats each, zero-filled once by the owner.
+size_t vort_elems(const FsGrid& g);
+void find_vort(hipStream_t st, const FsGrid& g, float* vortx, float* vorty, float* vortz, const float* ux,
+               const float* uy, const float* uz);
+void vort_confine(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* vortx,
+                  const float* vorty, const float* vortz, float coeff);
 // sum over owned cells of (div + 6p - neighbours)^2 in binary64; partial must hold
 // residual_partials(g) doubles, out one double.
 int residual_partials(const FsGrid& g);

@@ -126,6 +126,7 @@ struct fs_solver {
     int device = 0;
     hipStream_t st = nullptr;         // compute stream
     float* pool = nullptr;            // one allocation holding all 13 fields
+    float* vort[3] = {};              // dense vorticity arrays (one allocation), FS_FLAG_VORT_CONFINE only
     size_t field_elems = 0;           // floats per field including slack and ghost planes
     size_t origin = 0;                // offset of element (0,0,z0) inside a field
     float* host[FS_NUM_FIELDS] = {};  // pinned dense host copies, allocated on first use
@@ -483,6 +484,9 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         return fail(FS_ERR_INVALID, "fs_create_slab: rank %d of %d", rank, world);
     if (world > 1 && !unique_id && !fn)
         return fail(FS_ERR_INVALID, "fs_create_slab: neither an RCCL id nor an exchange function");
+    if (world > 1 && (p->flags & FS_FLAG_VORT_CONFINE))
+        return fail(FS_ERR_INVALID, "fs_create_slab: FS_FLAG_VORT_CONFINE is single-GPU only (its gathers "
+                                    "mix z planes through mismatched strides)");
     const int ghost = world > 1 ? 4 : 2;
     // z-slabs: the first nz % world ranks get one plane more
     const int base = p->nz / world, extra = p->nz % world;
@@ -557,6 +561,17 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         if (hipMemsetAsync(s->pool, 0, bytes, s->st) != hipSuccess) {
             rc = fail(FS_ERR_HIP, "fs_create: hipMemset failed");
             break;
+        }
+        if (p->flags & FS_FLAG_VORT_CONFINE) {
+            const size_t nv = fsk::vort_elems(g);
+            e = hipMalloc((void**)&s->vort[0], 3 * nv * sizeof(float));
+            if (e != hipSuccess || hipMemsetAsync(s->vort[0], 0, 3 * nv * sizeof(float), s->st) != hipSuccess) {
+                rc = fail(FS_ERR_HIP, "fs_create: vorticity arrays (%zu bytes): %s", 3 * nv * sizeof(float),
+                          hipGetErrorString(e));
+                break;
+            }
+            s->vort[1] = s->vort[0] + nv;
+            s->vort[2] = s->vort[1] + nv;
         }
         float** slots[nfields] = {&s->f.ux, &s->f.uy, &s->f.uz, &s->f.nux, &s->f.nuy, &s->f.nuz,
                                   &s->f.rho, &s->f.nrho, &s->f.T, &s->f.nT, &s->f.p, &s->f.np,
@@ -654,6 +669,7 @@ int fs_default_params(fs_params* p, int nx, int ny, int nz)
     p->tolerance = 0.f;
     p->check_every = 8;
     p->max_sweeps = 10000;
+    p->curl_strength = 0.1f;   // Solver.h:73
     return FS_OK;
 }
 
@@ -682,6 +698,7 @@ int fs_destroy(fs_solver* s)
     if (s->d_res) (void)hipFree(s->d_res);
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->pool) (void)hipFree(s->pool);
+    if (s->vort[0]) (void)hipFree(s->vort[0]);
     if (s->cs) (void)hipStreamDestroy(s->cs);
     if (s->st) (void)hipStreamDestroy(s->st);
     delete s;
@@ -740,6 +757,30 @@ int fs_stage_force(fs_solver* s)
     FS_HIP(hipSetDevice(s->device));
     StageScope sc(s, FS_STAGE_FORCE, 1);
     fsk::force_uy(s->st, s->g, s->f.uy, s->f.T, s->prm.dt, s->prm.temperature_env);
+    s->vel_ghost_ok = false;
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+int fs_stage_vorticity(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    if (!(s->prm.flags & FS_FLAG_VORT_CONFINE)) return FS_OK;
+    FS_HIP(hipSetDevice(s->device));
+    StageScope sc(s, FS_STAGE_VORTICITY, 1);
+    fsk::find_vort(s->st, s->g, s->vort[0], s->vort[1], s->vort[2], s->f.ux, s->f.uy, s->f.uz);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+int fs_stage_confine(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    if (!(s->prm.flags & FS_FLAG_VORT_CONFINE)) return FS_OK;
+    FS_HIP(hipSetDevice(s->device));
+    StageScope sc(s, FS_STAGE_CONFINE, 3);
+    fsk::vort_confine(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->vort[0], s->vort[1], s->vort[2],
+                      s->prm.curl_strength);
     s->vel_ghost_ok = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -847,7 +888,9 @@ static int step_eager(fs_solver* s)
     int rc;
     if ((rc = fs_stage_source(s))) return rc;
     if ((rc = fs_stage_force(s))) return rc;
+    if ((rc = fs_stage_vorticity(s))) return rc;
     if ((rc = fs_stage_advect(s))) return rc;
+    if ((rc = fs_stage_confine(s))) return rc;
     if ((rc = fs_stage_project(s))) return rc;
     return fs_stage_gradient(s);
 }

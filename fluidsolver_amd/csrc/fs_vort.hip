@@ -1,0 +1,217 @@
+// fs_vort.hip -- vorticity confinement (optional stage, single GPU), defined-behaviour variant.
+//
+// Reference: CuSolver/Source/Solver.cu FindVortx/y/z :485-525 (launched :1035-1037, before the
+// advection) and ApplyVortConfinement :540-605 (launched :1078-1080, after it).  The reference
+// writes each vorticity array with cell strides (nx, nx*ny) into nx*ny*nz floats but gathers from
+// it with the strides and clamps of an (nx,ny+1,nz+1) / (nx+1,ny,nz+1) / (nx+1,ny+1,nz) array
+// (:556-558), which runs past the allocation.  Here each array holds (nx+1)(ny+1)(nz+1) floats,
+// zeroed once at creation and written only in its first nx*ny*nz, so the same index arithmetic
+// stays in bounds and finds either a vorticity value or zero.  Everything else is literal:
+// mismatched strides, the launch-dimension-dependent guard (:548), float sqrt for the magnitudes,
+// the double-precision sqrt(... + 1e-5) (:593), true divisions.
+//
+// The arrays are dense (no row padding): the reference's flat indices are used as they are.
+#include "fs_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// clamped point sample of a staggered velocity component in the padded device layout
+// (sample(), Solver.cu:30-34)
+__device__ __forceinline__ float vel(const float* __restrict__ f, int x, int y, int z, int dx, int dy,
+                                     int dz, int pitch, int plane)
+{
+    x = max(0, min(x, dx - 1));
+    y = max(0, min(y, dy - 1));
+    z = max(0, min(z, dz - 1));
+    return f[x + y * pitch + z * plane];
+}
+
+// Solver.cu:485-525, all three components in one pass
+__global__ void k_find_vort(float* __restrict__ vortx, float* __restrict__ vorty, float* __restrict__ vortz,
+                            const float* __restrict__ ux, const float* __restrict__ uy,
+                            const float* __restrict__ uz, int nx, int ny, int nz, int pitch, int plane)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i >= nx || j >= ny) return;
+    const size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * ny;
+    {   // :492-496
+        float ubh = vel(uy, i, j, k - 1, nx, ny + 1, nz, pitch, plane);
+        float uf = vel(uy, i, j, k, nx, ny + 1, nz, pitch, plane);
+        float ubo = vel(uz, i, j - 1, k, nx, ny, nz + 1, pitch, plane);
+        float ut = vel(uz, i, j, k, nx, ny, nz + 1, pitch, plane);
+        vortx[ind] = uf - ubh - ut + ubo;
+    }
+    {   // :506-510
+        float ul = vel(uz, i - 1, j, k, nx, ny, nz + 1, pitch, plane);
+        float ur = vel(uz, i, j, k, nx, ny, nz + 1, pitch, plane);
+        float ubh = vel(ux, i, j, k - 1, nx + 1, ny, nz, pitch, plane);
+        float uf = vel(ux, i, j, k, nx + 1, ny, nz, pitch, plane);
+        vorty[ind] = ur - ul - uf + ubh;
+    }
+    {   // :520-524
+        float ul = vel(uy, i - 1, j, k, nx, ny + 1, nz, pitch, plane);
+        float ur = vel(uy, i, j, k, nx, ny + 1, nz, pitch, plane);
+        float ubo = vel(ux, i, j - 1, k, nx + 1, ny, nz, pitch, plane);
+        float ut = vel(ux, i, j, k, nx + 1, ny, nz, pitch, plane);
+        vortz[ind] = ut - ubo - ur + ul;
+    }
+}
+
+// One vorticity array as the gathers see it: dims (dx,dy,dz) give both the clamp and the strides.
+struct VortView {
+    const float* __restrict__ f;
+    int dx, dy, dz;
+};
+
+// Index contributions of the taps i-1, i, i+1 (and j, k alike) of one view, clamped like sample().
+struct VortTaps {
+    int x[3], y[3], z[3];
+};
+
+__device__ __forceinline__ VortTaps make_taps(const VortView& v, int i, int j, int k)
+{
+    VortTaps t;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        t.x[o] = max(0, min(i + o - 1, v.dx - 1));
+        t.y[o] = max(0, min(j + o - 1, v.dy - 1)) * v.dx;
+        t.z[o] = max(0, min(k + o - 1, v.dz - 1)) * v.dx * v.dy;
+    }
+    return t;
+}
+
+// lerp(a, b, s) = a*(1-s) + b*s (Math.cuh:57-60) for the two weights that occur here.  With s = 0
+// the result is a for every finite b (a*1 + b*0), so b is not loaded.
+template <bool HALF>
+__device__ __forceinline__ float lerp_s(float a, float b)
+{
+    if constexpr (HALF) return a * (1.0f - 0.5f) + b * 0.5f;
+    else return a;
+}
+
+// trilerp (Solver.cu:52-113, clamped samples) at a point whose coordinates, after the array's
+// staggering offset is subtracted, are (i,j,k) + (HX,HY,HZ)/2 with i,j,k >= 3: all coordinates are
+// positive, so int() and floor() agree, the lower tap is i + floor(H/2) and the weight is 0 or
+// one half according to the parity of H -- both known at compile time.  Identical taps of
+// different gathers are loaded once (same address expression, no store in between).
+template <int HX, int HY, int HZ>
+__device__ __forceinline__ float gather(const VortView& v, const VortTaps& t)
+{
+    constexpr int ox = (HX >> 1) + 1, oy = (HY >> 1) + 1, oz = (HZ >> 1) + 1;   // 0..2, arithmetic shift = floor
+    constexpr bool fx = HX & 1, fy = HY & 1, fz = HZ & 1;
+    static_assert(ox >= 0 && ox + fx <= 2 && oy >= 0 && oy + fy <= 2 && oz >= 0 && oz + fz <= 2, "tap range");
+    auto tap = [&](int a, int b, int c) { return v.f[t.x[a] + t.y[b] + t.z[c]]; };
+    auto row = [&](int b, int c) {
+        if constexpr (fx) return lerp_s<true>(tap(ox, b, c), tap(ox + 1, b, c));
+        else return tap(ox, b, c);
+    };
+    auto slab = [&](int c) {
+        if constexpr (fy) return lerp_s<true>(row(oy, c), row(oy + 1, c));
+        else return row(oy, c);
+    };
+    if constexpr (fz) return lerp_s<true>(slab(oz), slab(oz + 1));
+    else return slab(oz);
+}
+
+// |omega| at face position + (DX,DY,DZ)/2, Solver.cu:556-584.  PX,PY,PZ: twice the face's
+// staggering (0 on the component's own axis, 1 elsewhere); the arrays are staggered by one half
+// along x (vortx), y (vorty), z (vortz).
+template <int PX, int PY, int PZ, int DX, int DY, int DZ>
+__device__ __forceinline__ void vort3(const VortView& vx, const VortTaps& tx, const VortView& vy,
+                                      const VortTaps& ty, const VortView& vz, const VortTaps& tz,
+                                      float& ox, float& oy, float& oz)
+{
+    ox = gather<PX + DX - 1, PY + DY, PZ + DZ>(vx, tx);
+    oy = gather<PX + DX, PY + DY - 1, PZ + DZ>(vy, ty);
+    oz = gather<PX + DX, PY + DY, PZ + DZ - 1>(vz, tz);
+}
+
+template <int PX, int PY, int PZ, int DX, int DY, int DZ>
+__device__ __forceinline__ float vort_norm(const VortView& vx, const VortTaps& tx, const VortView& vy,
+                                           const VortTaps& ty, const VortView& vz, const VortTaps& tz)
+{
+    float a, b, c;
+    vort3<PX, PY, PZ, DX, DY, DZ>(vx, tx, vy, ty, vz, tz, a, b, c);
+    return sqrtf(a * a + b * b + c * c);
+}
+
+// Solver.cu:540-605 for component DIR (1: ux, 2: uy, 3: uz); (dx,dy,dz) are the dims of that
+// component, which are also the reference's launch dims, so the guard of :548 is literal.
+template <int DIR>
+__global__ void k_vort_confine(float* __restrict__ u, VortView vx, VortView vy, VortView vz, int dx, int dy,
+                               int dz, int pitch, int plane, float coeff)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (!(i > 2 && i < dx - 2 && j > 2 && j < dy - 2 && k > 2 && k < dz - 2)) return;
+    constexpr int PX = DIR == 1 ? 0 : 1, PY = DIR == 2 ? 0 : 1, PZ = DIR == 3 ? 0 : 1;
+    const VortTaps tx = make_taps(vx, i, j, k), ty = make_taps(vy, i, j, k), tz = make_taps(vz, i, j, k);
+
+    const float vt = vort_norm<PX, PY, PZ, 0, 1, 0>(vx, tx, vy, ty, vz, tz);
+    const float vbo = vort_norm<PX, PY, PZ, 0, -1, 0>(vx, tx, vy, ty, vz, tz);
+    const float vr = vort_norm<PX, PY, PZ, 1, 0, 0>(vx, tx, vy, ty, vz, tz);
+    const float vl = vort_norm<PX, PY, PZ, -1, 0, 0>(vx, tx, vy, ty, vz, tz);
+    const float vf = vort_norm<PX, PY, PZ, 0, 0, 1>(vx, tx, vy, ty, vz, tz);
+    const float vbh = vort_norm<PX, PY, PZ, 0, 0, -1>(vx, tx, vy, ty, vz, tz);
+    float vxc, vyc, vzc;
+    vort3<PX, PY, PZ, 0, 0, 0>(vx, tx, vy, ty, vz, tz, vxc, vyc, vzc);
+
+    float gx = vr - vl;
+    float gy = vt - vbo;
+    float gz = vf - vbh;
+    // :593 -- the float sum meets a double literal: widened, double sqrt, narrowed on assignment
+    const float n = (float)sqrt((double)(gx * gx + gy * gy + gz * gz) + 1e-5);
+    gx /= n;
+    gy /= n;
+    gz /= n;
+    float* dst = u + i + j * pitch + k * plane;
+    if (DIR == 1) *dst += coeff * (gy * vzc - gz * vyc);
+    else if (DIR == 2) *dst += coeff * (gz * vxc - gx * vzc);
+    else *dst += coeff * (gx * vyc - gy * vxc);
+}
+
+}  // namespace
+
+namespace fsk {
+
+size_t vort_elems(const FsGrid& g) { return (size_t)(g.nx + 1) * (size_t)(g.ny + 1) * (size_t)(g.nz + 1); }
+
+void find_vort(hipStream_t st, const FsGrid& g, float* vortx, float* vorty, float* vortz, const float* ux,
+               const float* uy, const float* uz)
+{
+    dim3 block(64, 4), grid(cdiv(g.nx, 64), cdiv(g.ny, 4), g.nz);
+    hipLaunchKernelGGL(k_find_vort, grid, block, 0, st, vortx, vorty, vortz, ux, uy, uz, g.nx, g.ny, g.nz,
+                       g.pitch, g.plane);
+}
+
+void vort_confine(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* vortx,
+                  const float* vorty, const float* vortz, float coeff)
+{
+    const VortView vx{vortx, g.nx, g.ny + 1, g.nz + 1}, vy{vorty, g.nx + 1, g.ny, g.nz + 1},
+        vz{vortz, g.nx + 1, g.ny + 1, g.nz};
+    dim3 block(64, 4);
+    {
+        const int dx = g.nx + 1, dy = g.ny, dz = g.nz;
+        hipLaunchKernelGGL(k_vort_confine<1>, dim3(cdiv(dx, 64), cdiv(dy, 4), dz), block, 0, st, ux, vx, vy, vz,
+                           dx, dy, dz, g.pitch, g.plane, coeff);
+    }
+    {
+        const int dx = g.nx, dy = g.ny + 1, dz = g.nz;
+        hipLaunchKernelGGL(k_vort_confine<2>, dim3(cdiv(dx, 64), cdiv(dy, 4), dz), block, 0, st, uy, vx, vy, vz,
+                           dx, dy, dz, g.pitch, g.plane, coeff);
+    }
+    {
+        const int dx = g.nx, dy = g.ny, dz = g.nz + 1;
+        hipLaunchKernelGGL(k_vort_confine<3>, dim3(cdiv(dx, 64), cdiv(dy, 4), dz), block, 0, st, uz, vx, vy, vz,
+                           dx, dy, dz, g.pitch, g.plane, coeff);
+    }
+}
+
+}  // namespace fsk

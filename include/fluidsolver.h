@@ -51,7 +51,14 @@ enum { FS_SCHEME_RK4 = 0, FS_SCHEME_MACCORMACK = 1 };
 /* fs_params.flags */
 enum {
     FS_FLAG_NO_GRAPH = 1 << 0,   /* launch kernels eagerly instead of replaying a hipGraph */
-    FS_FLAG_JACOBI_NAIVE = 1 << 1 /* one kernel launch per sweep, no temporal blocking */
+    FS_FLAG_JACOBI_NAIVE = 1 << 1, /* one kernel launch per sweep, no temporal blocking */
+    /* Vorticity confinement, Solver.cu:13 VORT_CONFINE (shipped as 1; off on the Jacobi hot path):
+       FindVortx/y/z after the buoyancy (Solver.cu:1035-1037), ApplyVortConfinement after the
+       advection (Solver.cu:1078-1080).  The reference gathers from its vorticity arrays beyond
+       their allocation (Solver.cu:556-558 against :894-896); this build gives the same index
+       arithmetic arrays of (nx+1)(ny+1)(nz+1) zero-initialised floats, so every read is defined.
+       Single GPU only. */
+    FS_FLAG_VORT_CONFINE = 1 << 2
 };
 
 /*
@@ -79,6 +86,7 @@ typedef struct fs_params {
     float tolerance;
     int check_every;
     int max_sweeps;
+    float curl_strength;         /* Solver.h:73   0.1, used with FS_FLAG_VORT_CONFINE */
 } fs_params;
 
 /* Device-side layout of one field (all fields of a solver share the strides). */
@@ -136,7 +144,9 @@ FS_API int fs_frame(const fs_solver* s);          /* Solver.h:76 current_frame *
       kernel launches at Solver.cu:1028, 1031 and 1111-1113. -- */
 FS_API int fs_stage_source(fs_solver* s);         /* SourceKernel      Solver.cu:295-307 */
 FS_API int fs_stage_force(fs_solver* s);          /* ForceKernelUy     Solver.cu:346-368 */
+FS_API int fs_stage_vorticity(fs_solver* s);      /* FindVortx/y/z     Solver.cu:485-525, 1035-1037; no-op without FS_FLAG_VORT_CONFINE */
 FS_API int fs_stage_advect(fs_solver* s);         /* Solver::Advect    Solver.cu:1145-1165 */
+FS_API int fs_stage_confine(fs_solver* s);        /* ApplyVortConfinement Solver.cu:540-605, 1078-1080; no-op without the flag */
 FS_API int fs_stage_divergence(fs_solver* s);     /* DivergenceKernel  Solver.cu:406-423 */
 FS_API int fs_stage_jacobi(fs_solver* s, int sweeps); /* JacobiKernel + swap, Solver.cu:426-443, 1180-1184 */
 FS_API int fs_stage_project(fs_solver* s);        /* Solver::Project   Solver.cu:1168-1189 */
@@ -172,7 +182,8 @@ FS_API int fs_last_sweeps(const fs_solver* s);
       it made, so  ms_total / launches  is the average launch duration. -- */
 enum {
     FS_STAGE_SOURCE = 0, FS_STAGE_FORCE, FS_STAGE_ADVECT_VELOCITY, FS_STAGE_ADVECT_SCALARS,
-    FS_STAGE_DIVERGENCE, FS_STAGE_JACOBI, FS_STAGE_GRADIENT, FS_NUM_STAGES
+    FS_STAGE_DIVERGENCE, FS_STAGE_JACOBI, FS_STAGE_GRADIENT, FS_STAGE_VORTICITY, FS_STAGE_CONFINE,
+    FS_NUM_STAGES
 };
 FS_API int fs_profile_enable(fs_solver* s, int on);
 FS_API int fs_profile_read(fs_solver* s, int stage, double* ms_total, long long* launches);

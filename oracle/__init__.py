@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "libfs_oracle.so")
 
 SCHEME_RK4 = 0
 SCHEME_MACCORMACK = 1
-UX, UY, UZ, RHO, T, P, DIV, R = range(8)
+UX, UY, UZ, RHO, T, P, DIV, R, VORTX, VORTY, VORTZ = range(11)
 FIELD_NAMES = {UX: "ux", UY: "uy", UZ: "uz", RHO: "rho", T: "T", P: "p", DIV: "div", R: "r"}
 
 
@@ -28,6 +28,7 @@ class Params(C.Structure):
         ("source_x", C.c_float), ("source_y", C.c_float), ("source_z", C.c_float),
         ("source_radius", C.c_float),
         ("rho0", C.c_float), ("temperature0", C.c_float), ("temperature_env", C.c_float),
+        ("vort_confine", C.c_int), ("curl_strength", C.c_float),
     ]
 
 
@@ -55,7 +56,8 @@ def lib():
     L.fso_create.argtypes = [C.POINTER(Params)]
     L.fso_create.restype = C.c_void_p
     for name in ("fso_destroy", "fso_step", "fso_stage_source", "fso_stage_force",
-                 "fso_stage_advect", "fso_stage_project", "fso_stage_gradient"):
+                 "fso_stage_advect", "fso_stage_project", "fso_stage_gradient",
+                 "fso_stage_vorticity", "fso_stage_confine"):
         getattr(L, name).argtypes = [C.c_void_p]
         getattr(L, name).restype = None
     L.fso_field.argtypes = [C.c_void_p, C.c_int]
@@ -84,6 +86,12 @@ def lib():
     L.fso_gradient.restype = None
     L.fso_sum_sq.argtypes = [_fp, C.c_size_t]
     L.fso_sum_sq.restype = C.c_double
+    L.fso_vort_size.argtypes = [C.c_int] * 3
+    L.fso_vort_size.restype = C.c_size_t
+    L.fso_find_vort.argtypes = [_fp] * 6 + [C.c_int] * 3
+    L.fso_find_vort.restype = None
+    L.fso_vort_confine.argtypes = [_fp] * 4 + [C.c_int] * 4 + [C.c_float]
+    L.fso_vort_confine.restype = None
     _lib = L
     return L
 
@@ -101,6 +109,8 @@ def field_shape(which, nx, ny, nz):
         return (nz, ny + 1, nx)
     if which == UZ:
         return (nz + 1, ny, nx)
+    if which in (VORTX, VORTY, VORTZ):
+        return ((nz + 1) * (ny + 1) * (nx + 1),)      # flat: written and read with different strides
     return (nz, ny, nx)
 
 
@@ -213,3 +223,22 @@ def gradient(ux, uy, uz, p):
 
 def sum_sq(r):
     return lib().fso_sum_sq(_p(r), r.size)
+
+
+def vort_size(nx, ny, nz):
+    return lib().fso_vort_size(nx, ny, nz)
+
+
+def find_vort(ux, uy, uz):
+    """The three vorticity arrays (flat, (nx+1)(ny+1)(nz+1) floats each, zero beyond nx*ny*nz)."""
+    nz, ny, nx = ux.shape[0], ux.shape[1], ux.shape[2] - 1
+    n = vort_size(nx, ny, nz)
+    vx, vy, vz = (np.zeros(n, np.float32) for _ in range(3))
+    lib().fso_find_vort(_p(vx), _p(vy), _p(vz), _p(ux), _p(uy), _p(uz), nx, ny, nz)
+    return vx, vy, vz
+
+
+def vort_confine(u, vx, vy, vz, dims, dir_, coeff):
+    """In-place confinement force on one velocity component (dir_ 1, 2, 3)."""
+    nx, ny, nz = dims
+    lib().fso_vort_confine(_p(u), _p(vx), _p(vy), _p(vz), nx, ny, nz, dir_, coeff)

@@ -327,6 +327,107 @@ void fso_gradient(float* ux, float* uy, float* uz, const float* pressure, int nx
             }
 }
 
+/* --------------------------------------------------- vorticity confinement (optional) */
+
+/* Size of each vorticity array in the defined-behaviour variant.  The reference writes its
+ * vorticity arrays with cell strides (nx, nx*ny) into nx*ny*nz floats (Solver.cu:485-525,
+ * 894-896) but reads them with the strides of (nx,ny+1,nz+1), (nx+1,ny,nz+1) and (nx+1,ny+1,nz)
+ * arrays (Solver.cu:556-558), i.e. beyond the allocation.  Here the arrays hold
+ * (nx+1)(ny+1)(nz+1) floats, zero-filled once, so every such read is in bounds and returns either
+ * a vorticity value (through the mismatched strides, as in the reference) or zero. */
+size_t fso_vort_size(int nx, int ny, int nz)
+{
+    return (size_t)(nx + 1) * (size_t)(ny + 1) * (size_t)(nz + 1);
+}
+
+/* Solver.cu:485-525, launches :1035-1037 <<<(ny,nz), nx>>>: ind = i + j*nx + k*nx*ny */
+void fso_find_vort(float* vortx, float* vorty, float* vortz, const float* ux, const float* uy,
+                   const float* uz, int nx, int ny, int nz)
+{
+    const i3 max_pos_ux = mk_i3(nx + 1, ny, nz), max_pos_uy = mk_i3(nx, ny + 1, nz),
+             max_pos_uz = mk_i3(nx, ny, nz + 1);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * ny;
+                {   /* FindVortx :492-496 */
+                    float ubh = sample(uy, mk_i3(i, j, k - 1), max_pos_uy);
+                    float uf = sample(uy, mk_i3(i, j, k), max_pos_uy);
+                    float ubo = sample(uz, mk_i3(i, j - 1, k), max_pos_uz);
+                    float ut = sample(uz, mk_i3(i, j, k), max_pos_uz);
+                    vortx[ind] = uf - ubh - ut + ubo;
+                }
+                {   /* FindVorty :506-510 */
+                    float ul = sample(uz, mk_i3(i - 1, j, k), max_pos_uz);
+                    float ur = sample(uz, mk_i3(i, j, k), max_pos_uz);
+                    float ubh = sample(ux, mk_i3(i, j, k - 1), max_pos_ux);
+                    float uf = sample(ux, mk_i3(i, j, k), max_pos_ux);
+                    vorty[ind] = ur - ul - uf + ubh;
+                }
+                {   /* FindVortz :520-524 */
+                    float ul = sample(uy, mk_i3(i - 1, j, k), max_pos_uy);
+                    float ur = sample(uy, mk_i3(i, j, k), max_pos_uy);
+                    float ubo = sample(ux, mk_i3(i, j - 1, k), max_pos_ux);
+                    float ut = sample(ux, mk_i3(i, j, k), max_pos_ux);
+                    vortz[ind] = ut - ubo - ur + ul;
+                }
+            }
+}
+
+/* the three gathers at one point, Solver.cu:556-558 and its repetitions */
+static inline f3 vort_at(const float* vortx, const float* vorty, const float* vortz, float px,
+                         float py, float pz, int nx, int ny, int nz)
+{
+    f3 v, pos = mk_f3(px, py, pz);
+    v.x = trilerp(vortx, pos, 0.5f, 0.f, 0.f, mk_i3(nx, ny + 1, nz + 1), 1);
+    v.y = trilerp(vorty, pos, 0.f, 0.5f, 0.f, mk_i3(nx + 1, ny, nz + 1), 1);
+    v.z = trilerp(vortz, pos, 0.f, 0.f, 0.5f, mk_i3(nx + 1, ny + 1, nz), 1);
+    return v;
+}
+
+/* sqrt of a float argument is the float overload in device code (:559 etc.) */
+static inline float vort_norm(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+
+/* Solver.cu:540-605, launches :1078-1080 with blockDim.x = dx, gridDim = (dy, dz) of the
+ * component: dir 1 (nx+1,ny,nz), dir 2 (nx,ny+1,nz), dir 3 (nx,ny,nz+1). */
+void fso_vort_confine(float* u, const float* vortx, const float* vorty, const float* vortz,
+                      int nx, int ny, int nz, int dir, float coeff)
+{
+    const int dx = nx + (dir == 1), dy = ny + (dir == 2), dz = nz + (dir == 3);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < dz; ++k)
+        for (int j = 0; j < dy; ++j)
+            for (int i = 0; i < dx; ++i) {
+                /* :548 -- the guard depends on the launch dims of this component */
+                if (!(i > 2 && i < dx - 2 && j > 2 && j < dy - 2 && k > 2 && k < dz - 2)) continue;
+                size_t ind = (size_t)i + (size_t)j * dx + (size_t)k * dx * dy;
+                float px = (float)i + (dir == 1 ? 0.f : 0.5f);          /* :552-554 */
+                float py = (float)j + (dir == 2 ? 0.f : 0.5f);
+                float pz = (float)k + (dir == 3 ? 0.f : 0.5f);
+                /* pos + 0.5 is evaluated in double and narrowed by combine_float3 (:556);
+                   halves of small integers are exact either way */
+                float vt = vort_norm(vort_at(vortx, vorty, vortz, px, (float)((double)py + 0.5), pz, nx, ny, nz));
+                float vbo = vort_norm(vort_at(vortx, vorty, vortz, px, (float)((double)py - 0.5), pz, nx, ny, nz));
+                float vr = vort_norm(vort_at(vortx, vorty, vortz, (float)((double)px + 0.5), py, pz, nx, ny, nz));
+                float vl = vort_norm(vort_at(vortx, vorty, vortz, (float)((double)px - 0.5), py, pz, nx, ny, nz));
+                float vf = vort_norm(vort_at(vortx, vorty, vortz, px, py, (float)((double)pz + 0.5), nx, ny, nz));
+                float vbh = vort_norm(vort_at(vortx, vorty, vortz, px, py, (float)((double)pz - 0.5), nx, ny, nz));
+                f3 vc = vort_at(vortx, vorty, vortz, px, py, pz, nx, ny, nz);   /* :586-588 */
+                float gx = vr - vl;                                      /* :590-592 */
+                float gy = vt - vbo;
+                float gz = vf - vbh;
+                /* :593 -- the float sum is widened by the double literal, double sqrt, narrowed */
+                float n = (float)sqrt((double)(gx * gx + gy * gy + gz * gz) + 1e-5);
+                gx /= n;                                                 /* :594-596 */
+                gy /= n;
+                gz /= n;
+                if (dir == 1) u[ind] += coeff * (gy * vc.z - gz * vc.y);        /* :598-603 */
+                else if (dir == 2) u[ind] += coeff * (gz * vc.x - gx * vc.z);
+                else u[ind] += coeff * (gx * vc.y - gy * vc.x);
+            }
+}
+
 /* What Solver.cu:1185-1187 (Mul + Reduce) is meant to produce: sum of r*r over the grid.
    The reference's fp32 tree drops elements at most sizes and races in place, so the
    defined target is the mathematically plain sum, accumulated in binary64. */
@@ -344,6 +445,7 @@ struct fso_state {
     float *ux, *uy, *uz, *new_ux, *new_uy, *new_uz;
     float *rho, *new_rho, *temperature, *new_temperature;
     float *pressure, *new_pressure, *div, *r;
+    float *vortx, *vorty, *vortz;   /* only with vort_confine */
     int frame;
 };
 
@@ -361,6 +463,8 @@ void fso_default_params(fso_params* p, int nx, int ny, int nz)
     p->source_z = nz / 2.f;                      /* Solver.h:80 */
     p->source_radius = 7.0f;                     /* Solver.h:81 */
     p->scheme = FSO_SCHEME_MACCORMACK;           /* Solver.cu:11 */
+    p->vort_confine = 0;                         /* Solver.cu:13 ships 1; off on the Jacobi hot path */
+    p->curl_strength = 0.1f;                     /* Solver.h:73 */
 }
 
 static float* zalloc(size_t n) { return (float*)calloc(n ? n : 1, sizeof(float)); }
@@ -379,6 +483,10 @@ fso_state* fso_create(const fso_params* p)
     s->temperature = zalloc(n);  s->new_temperature = zalloc(n);
     s->pressure = zalloc(n);     s->new_pressure = zalloc(n);
     s->div = zalloc(n);          s->r = zalloc(n);
+    if (p->vort_confine) {
+        size_t nv = fso_vort_size(p->nx, p->ny, p->nz);
+        s->vortx = zalloc(nv); s->vorty = zalloc(nv); s->vortz = zalloc(nv);
+    }
     fso_grid_init(s->temperature, p->temperature_env, p->nx, p->ny, p->nz);
     return s;
 }
@@ -389,6 +497,7 @@ void fso_destroy(fso_state* s)
     free(s->ux); free(s->uy); free(s->uz); free(s->new_ux); free(s->new_uy); free(s->new_uz);
     free(s->rho); free(s->new_rho); free(s->temperature); free(s->new_temperature);
     free(s->pressure); free(s->new_pressure); free(s->div); free(s->r);
+    free(s->vortx); free(s->vorty); free(s->vortz);
     free(s);
 }
 
@@ -441,12 +550,32 @@ void fso_stage_gradient(fso_state* s)
     fso_gradient(s->ux, s->uy, s->uz, s->pressure, p->nx, p->ny, p->nz);       /* :1111-1113 */
 }
 
-/* Solver.cu:1009-1114 with VORT_CONFINE/IVOCK/REFLECT/BURST all 0, then :1136 */
+/* u -> omega, Solver.cu:1035-1037 (no-op unless vort_confine) */
+void fso_stage_vorticity(fso_state* s)
+{
+    const fso_params* p = &s->p;
+    if (!p->vort_confine) return;
+    fso_find_vort(s->vortx, s->vorty, s->vortz, s->ux, s->uy, s->uz, p->nx, p->ny, p->nz);
+}
+
+/* Solver.cu:1078-1080 (no-op unless vort_confine) */
+void fso_stage_confine(fso_state* s)
+{
+    const fso_params* p = &s->p;
+    if (!p->vort_confine) return;
+    fso_vort_confine(s->ux, s->vortx, s->vorty, s->vortz, p->nx, p->ny, p->nz, 1, p->curl_strength);
+    fso_vort_confine(s->uy, s->vortx, s->vorty, s->vortz, p->nx, p->ny, p->nz, 2, p->curl_strength);
+    fso_vort_confine(s->uz, s->vortx, s->vorty, s->vortz, p->nx, p->ny, p->nz, 3, p->curl_strength);
+}
+
+/* Solver.cu:1009-1114 with IVOCK/REFLECT/BURST 0 and VORT_CONFINE = p.vort_confine, then :1136 */
 void fso_step(fso_state* s)
 {
     fso_stage_source(s);
     fso_stage_force(s);
+    fso_stage_vorticity(s);
     fso_stage_advect(s);
+    fso_stage_confine(s);
     fso_stage_project(s);
     fso_stage_gradient(s);
     s->frame++;
@@ -463,6 +592,9 @@ float* fso_field(fso_state* s, int which)
     case FSO_P: return s->pressure;
     case FSO_DIV: return s->div;
     case FSO_R: return s->r;
+    case FSO_VORTX: return s->vortx;
+    case FSO_VORTY: return s->vorty;
+    case FSO_VORTZ: return s->vortz;
     default: return NULL;
     }
 }
@@ -475,6 +607,8 @@ size_t fso_field_size(const fso_state* s, int which)
     case FSO_UY: return nx * (ny + 1) * nz;
     case FSO_UZ: return nx * ny * (nz + 1);
     case FSO_RHO: case FSO_T: case FSO_P: case FSO_DIV: case FSO_R: return nx * ny * nz;
+    case FSO_VORTX: case FSO_VORTY: case FSO_VORTZ:
+        return s->p.vort_confine ? fso_vort_size(s->p.nx, s->p.ny, s->p.nz) : 0;
     default: return 0;
     }
 }

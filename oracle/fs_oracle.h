@@ -13,7 +13,8 @@ extern "C" {
 #endif
 
 enum { FSO_SCHEME_RK4 = 0, FSO_SCHEME_MACCORMACK = 1 };
-enum { FSO_UX = 0, FSO_UY = 1, FSO_UZ = 2, FSO_RHO = 3, FSO_T = 4, FSO_P = 5, FSO_DIV = 6, FSO_R = 7 };
+enum { FSO_UX = 0, FSO_UY = 1, FSO_UZ = 2, FSO_RHO = 3, FSO_T = 4, FSO_P = 5, FSO_DIV = 6, FSO_R = 7,
+       FSO_VORTX = 8, FSO_VORTY = 9, FSO_VORTZ = 10 };
 
 typedef struct fso_params {
     int nx, ny, nz;
@@ -22,6 +23,8 @@ typedef struct fso_params {
     int scheme;
     float source_x, source_y, source_z, source_radius;
     float rho0, temperature0, temperature_env;
+    int vort_confine;        /* Solver.cu:13 VORT_CONFINE, defined-behaviour variant (see fso_vort_size) */
+    float curl_strength;     /* Solver.h:73 */
 } fso_params;
 
 typedef struct fso_state fso_state;
@@ -32,7 +35,9 @@ void fso_destroy(fso_state* s);
 void fso_step(fso_state* s);
 void fso_stage_source(fso_state* s);
 void fso_stage_force(fso_state* s);
+void fso_stage_vorticity(fso_state* s);
 void fso_stage_advect(fso_state* s);
+void fso_stage_confine(fso_state* s);
 void fso_stage_project(fso_state* s);
 void fso_stage_gradient(fso_state* s);
 float* fso_field(fso_state* s, int which);
@@ -58,6 +63,11 @@ void fso_jacobi(const float* field, float* new_field, const float* div_field, fl
                 int nx, int ny, int nz);
 void fso_gradient(float* ux, float* uy, float* uz, const float* pressure, int nx, int ny, int nz);
 double fso_sum_sq(const float* r, size_t n);
+size_t fso_vort_size(int nx, int ny, int nz);
+void fso_find_vort(float* vortx, float* vorty, float* vortz, const float* ux, const float* uy,
+                   const float* uz, int nx, int ny, int nz);
+void fso_vort_confine(float* u, const float* vortx, const float* vorty, const float* vortz,
+                      int nx, int ny, int nz, int dir, float coeff);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,7 @@ def test_default_params_mirror_reference_header(fs):
     assert abs(p.dt - 0.2) < 1e-7 and p.jacobi_iters == 30 and p.scheme == fs.FS_SCHEME_MACCORMACK
     assert (p.source_x, p.source_y, p.source_z, p.source_radius) == (32.0, 10.0, 32.0, 7.0)
     assert abs(p.source_rho - 0.1) < 1e-7 and p.source_temperature == 2.0 and p.temperature_env == 0.0
+    assert abs(p.curl_strength - 0.1) < 1e-7 and not (p.flags & fs.FS_FLAG_VORT_CONFINE)   # Solver.h:73
 
 
 def test_bad_arguments_are_reported(fs):

@@ -215,3 +215,62 @@ def test_default_params_match_reference_header(oracle):
     assert p.dt == F(0.2) and p.jacobi_iters == 30 and p.scheme == 1
     assert (p.source_x, p.source_y, p.source_z, p.source_radius) == (32.0, 10.0, 32.0, 7.0)
     assert p.rho0 == F(0.1) and p.temperature0 == 2.0 and p.temperature_env == 0.0
+
+
+# ------------------------------------------------------------ vorticity confinement variant
+
+def test_vorticity_of_rigid_rotation_and_layout(oracle):
+    """FindVortx/y/z (Solver.cu:485-525): for u = (-y', x', 0) sampled on the staggered grid the
+    z component is  ut - ubo - ur + ul = -1 - 1 = -2  in the interior, the others 0; the values sit
+    at the cell index i + j*nx + k*nx*ny and the rest of the (nx+1)(ny+1)(nz+1) array stays 0."""
+    nx, ny, nz = 6, 5, 4
+    ux = np.zeros((nz, ny, nx + 1), np.float32); uy = np.zeros((nz, ny + 1, nx), np.float32)
+    uz = np.zeros((nz + 1, ny, nx), np.float32)
+    ux[:, :, :] = -(np.arange(ny, dtype=np.float32) + 0.5)[None, :, None]     # -y at (i, j+.5)
+    uy[:, :, :] = (np.arange(nx, dtype=np.float32) + 0.5)[None, None, :]      # +x at (i+.5, j)
+    vx, vy, vz = oracle.find_vort(ux, uy, uz)
+    n = nx * ny * nz
+    assert vx.size == (nx + 1) * (ny + 1) * (nz + 1)
+    assert not vx[n:].any() and not vy[n:].any() and not vz[n:].any()
+    assert not vx[:n].any() and not vy[:n].any()
+    z = vz[:n].reshape(nz, ny, nx)
+    assert np.all(z[:, 1:, 1:] == -2.0)
+    # clamped neighbours at i = 0 / j = 0 (Solver.cu:520, 522): one of the two differences vanishes
+    assert np.all(z[:, 1:, 0] == -1.0) and np.all(z[:, 0, 1:] == -1.0) and np.all(z[:, 0, 0] == 0.0)
+
+
+def test_confinement_guard_and_zero_vorticity(oracle):
+    """ApplyVortConfinement (Solver.cu:540-605): zero vorticity gives n = sqrt(1e-5) and a zero
+    force; with a non-zero field only faces with 2 < index < launch_dim - 2 change (:548)."""
+    nx, ny, nz = 9, 8, 10
+    rng = np.random.default_rng(5)
+    for d, shape in ((1, (nz, ny, nx + 1)), (2, (nz, ny + 1, nx)), (3, (nz + 1, ny, nx))):
+        u0 = rng.standard_normal(shape).astype(np.float32)
+        zero = np.zeros(oracle.vort_size(nx, ny, nz), np.float32)
+        u = u0.copy()
+        oracle.vort_confine(u, zero, zero, zero, (nx, ny, nz), d, 0.1)
+        assert np.array_equal(u, u0)
+        vx, vy, vz = (rng.standard_normal(zero.size).astype(np.float32) for _ in range(3))
+        u = u0.copy()
+        oracle.vort_confine(u, vx, vy, vz, (nx, ny, nz), d, 0.1)
+        changed = u != u0
+        dz, dy, dx = shape
+        inner = np.zeros(shape, bool)
+        inner[3:dz - 2, 3:dy - 2, 3:dx - 2] = True
+        assert not changed[~inner].any()
+        assert changed[inner].mean() > 0.9
+
+
+def test_confinement_step_order(oracle):
+    """Solver.cu:1031-1082: vorticity from the post-buoyancy velocity, advection, confinement on
+    the advected velocity with that vorticity, then the projection."""
+    kw = dict(jacobi_iters=5, source_y=5.0, source_radius=3.0, vort_confine=1)
+    a = oracle.Oracle(oracle.default_params(12, 14, 10, **kw))
+    b = oracle.Oracle(oracle.default_params(12, 14, 10, **kw))
+    for _ in range(3):
+        a.step()
+        b.stage("source"); b.stage("force"); b.stage("vorticity"); b.stage("advect"); b.stage("confine")
+        b.stage("project"); b.stage("gradient")
+    for f in range(6):
+        assert np.array_equal(a.get(f), b.get(f))
+    a.close(); b.close()

@@ -246,3 +246,86 @@ def test_graph_replay_matches_eager_launches(fs, oracle, k):
     assert_all_equal(g, o, what="graph k=%d final" % k)
     assert_all_equal(e, o, what="eager k=%d final" % k)
     g.close(); e.close(); o.close()
+
+
+@pytest.mark.parametrize("dims", [(16, 20, 12), (9, 8, 10), (6, 6, 6), (70, 9, 11)])
+def test_vorticity_confinement_stages(fs, oracle, dims):
+    """FS_FLAG_VORT_CONFINE: FindVort + ApplyVortConfinement from a random state, against the
+    oracle's literal gathers (mismatched strides, guard from the launch dims, double sqrt)."""
+    nx, ny, nz = dims
+    g, o = make_pair(fs, oracle, nx, ny, nz, flags=fs.FS_FLAG_VORT_CONFINE)
+    o.close()
+    o = oracle.Oracle(oracle.default_params(nx, ny, nz, vort_confine=1))
+    st = random_fields(nx, ny, nz, seed=77, vel_scale=3.0)
+    load_state(g, o, st)
+    g.stage("vorticity"); o.stage("vorticity")
+    g.stage("confine"); o.stage("confine")
+    assert_all_equal(g, o, fields=range(3), what="confinement %s" % (dims,))
+    # second application with the same vorticity on the changed velocity
+    g.stage("confine"); o.stage("confine")
+    assert_all_equal(g, o, fields=range(3), what="confinement twice %s" % (dims,))
+    g.close(); o.close()
+
+
+def test_vorticity_confinement_full_steps(fs, oracle):
+    """The shipped reference build's step order (VORT_CONFINE 1) on a plume, graph replay on."""
+    nx, ny, nz = 32, 40, 28
+    kw = dict(jacobi_iters=12, source_y=8.0, source_radius=5.0)
+    g, o = make_pair(fs, oracle, nx, ny, nz, flags=fs.FS_FLAG_VORT_CONFINE, **kw)
+    o.close()
+    o = oracle.Oracle(oracle.default_params(nx, ny, nz, vort_confine=1, **kw))
+    for s in range(12):
+        g.step(); o.step()
+        if s in (0, 5, 11):
+            assert_all_equal(g, o, what="confined step %d" % (s + 1))
+    g.close(); o.close()
+
+
+def test_vorticity_confinement_rejected_on_slabs(fs):
+    import ctypes as C
+    L = fs.load_library()
+    p = fs.default_params(16, 16, 32, flags=fs.FS_FLAG_VORT_CONFINE)
+    h = C.c_void_p()
+    cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)(
+        lambda *a: 0)
+    rc = L.fs_create_slab(C.byref(p), 0, 2, None, cb, None, C.byref(h))
+    assert rc == -1 and b"single-GPU" in L.fs_last_error()
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_jacobi_division_on_hard_inputs(fs, oracle, cfg, monkeypatch):
+    """The fused kernel divides by 6 through a binary64 multiply; the oracle uses the true
+    division.  Inputs chosen to land on the hard cases: quotients that are exact ties of the
+    subnormal grid (x = 3*(2m+1)*2^-149), fields that are subnormal throughout, and random bit
+    patterns over the whole finite range (sums may overflow to infinity)."""
+    monkeypatch.setenv("FS_JACOBI_CFG", str(cfg))
+    nx, ny, nz = 72, 40, 12
+    rng = np.random.default_rng(123 + cfg)
+    shape = (nz, ny, nx)
+    tiny = np.float32(2.0 ** -149)
+
+    def run(p0, div, what):
+        g, o = make_pair(fs, oracle, nx, ny, nz, jacobi_iters=4)
+        load_state(g, o, {5: p0, 6: div})
+        g.stage("jacobi", 4)
+        p = p0
+        for _ in range(4):
+            p, _r = oracle.jacobi(p, div, want_r=False)
+        got = g.field(fs.FS_P)
+        ok = (got == p) | (np.isnan(got) & np.isnan(p))
+        assert ok.all(), "%s: %d mismatches, first gpu=%r oracle=%r" % (
+            what, int((~ok).sum()), got[~ok][0], p[~ok][0])
+        g.close(); o.close()
+
+    with np.errstate(all="ignore"):
+        m = rng.integers(0, 2 ** 20, shape)
+        ties = (3 * (2 * m + 1)).astype(np.float32) * tiny * rng.choice(np.float32([-1, 1]), shape)
+        run(np.zeros(shape, np.float32), -ties, "exact subnormal ties")
+        sub = rng.integers(-2 ** 22, 2 ** 22, shape).astype(np.float32) * tiny
+        run(sub, rng.integers(-2 ** 23, 2 ** 23, shape).astype(np.float32) * tiny, "subnormal fields")
+        bits = rng.integers(0, 2 ** 32, shape, dtype=np.uint64).astype(np.uint32)
+        bits[(bits >> 23) & 0xFF == 0xFF] &= np.uint32(0x807FFFFF)      # no inf / NaN inputs
+        p0 = bits.view(np.float32).copy()
+        bits2 = rng.integers(0, 2 ** 32, shape, dtype=np.uint64).astype(np.uint32)
+        bits2[(bits2 >> 23) & 0xFF == 0xFF] &= np.uint32(0x807FFFFF)
+        run(p0, bits2.view(np.float32).copy(), "random bit patterns")
