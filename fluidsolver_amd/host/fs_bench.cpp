@@ -2,12 +2,14 @@
 //   fs_bench [n=256] [sweeps=80] [steps=20] [warmup=5] [dump_prefix|-] [flags=0]
 // Prints one JSON line: cell-updates/s of `steps` steps and, from a second profiled run of as
 // many steps, the device time per stage.  With dump_prefix, writes
-// the final rho/ux/uy/uz as raw little-endian float32, x fastest (dense reference layout).
+// the final rho/ux/uy/uz as raw little-endian float32, x fastest (dense reference layout), and
+// <dump_prefix>.json describing them (read back by fluidsolver_amd.dump.read_dump).
 #include "fluidsolver.h"
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 static void die(const char* what)
@@ -54,8 +56,17 @@ int main(int argc, char** argv)
 	}
 	std::printf("}}\n");
 	if (dump) {
+		// raw little-endian float32, x fastest, plus a JSON sidecar naming dims and parameters
 		static const char* fn[4] = {"ux", "uy", "uz", "rho"};
 		static const int ids[4] = {FS_UX, FS_UY, FS_UZ, FS_RHO};
+		const int dims[4][3] = {{n + 1, n, n}, {n, n + 1, n}, {n, n, n + 1}, {n, n, n}};
+		std::string side = std::string(dump) + ".json";
+		FILE* js = std::fopen(side.c_str(), "w");
+		if (!js) { std::perror(side.c_str()); return 1; }
+		std::fprintf(js, "{\"format\": \"fluidsolver-f32-v1\", \"endian\": \"little\", \"order\": \"x-fastest\", "
+		                 "\"nx\": %d, \"ny\": %d, \"nz\": %d, \"frame\": %d, \"dt\": %.9g, \"jacobi_iters\": %d, "
+		                 "\"scheme\": %d, \"flags\": %u, \"fields\": {",
+		             n, n, n, fs_frame(s), p.dt, p.jacobi_iters, p.scheme, p.flags);
 		for (int q = 0; q < 4; ++q) {
 			const float* h = fs_field_host(s, ids[q]);
 			if (!h) die("fs_field_host");
@@ -64,7 +75,12 @@ int main(int argc, char** argv)
 			if (!f) { std::perror(path.c_str()); return 1; }
 			std::fwrite(h, sizeof(float), fs_field_size(s, ids[q]), f);
 			std::fclose(f);
+			const char* base = std::strrchr(path.c_str(), '/');
+			std::fprintf(js, "%s\"%s\": {\"file\": \"%s\", \"dims\": [%d, %d, %d]}", q ? ", " : "", fn[q],
+			             base ? base + 1 : path.c_str(), dims[q][0], dims[q][1], dims[q][2]);
 		}
+		std::fprintf(js, "}}\n");
+		std::fclose(js);
 	}
 	fs_destroy(s);
 	return 0;

@@ -9,6 +9,8 @@ give the GPU tests inputs/outputs that do not depend on building the oracle on t
 Files:
   plume16.npz  -- 16^3, K=20: all 7 fields after steps 1, 2, 10 (source moved inside the box)
   plume32.npz  -- 32^3, K=20: all 7 fields after steps 2 and 10
+  plume20_confined.npz -- 20^3, K=12, vorticity confinement on (defined-behaviour variant of the
+                          shipped VORT_CONFINE build): ux, uy, uz, rho after steps 3 and 8
   plume64_stats.npz -- 64^3, K=20, 100 steps: per-field sum (f64) / L2 / max / argmax every 10
                        steps, the rho centre line rho[nz/2, :, nx/2] and 4096 fixed probe points
                        (index list stored in the file) at steps 50 and 100
@@ -34,6 +36,18 @@ def small(n, steps_keep, sy, sr):
         if s in steps_keep:
             for f, name in enumerate(NAMES):
                 out["s%d_%s" % (s, name)] = o.get(f)
+    return out
+
+
+def confined(n, steps_keep):
+    kw = dict(jacobi_iters=12, source_y=6.0, source_radius=4.0)
+    o = oracle.Oracle(oracle.default_params(n, n, n, vort_confine=1, **kw))
+    out = {"n": n, **kw}
+    for s in range(1, max(steps_keep) + 1):
+        o.step()
+        if s in steps_keep:
+            for f in (0, 1, 2, 3):
+                out["s%d_%s" % (s, NAMES[f])] = o.get(f)
     return out
 
 
@@ -66,6 +80,7 @@ def stats64():
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "plume16.npz"), **small(16, (1, 2, 10), 5.0, 4.0))
     np.savez_compressed(os.path.join(HERE, "plume32.npz"), **small(32, (2, 10), 8.0, 5.0))
+    np.savez_compressed(os.path.join(HERE, "plume20_confined.npz"), **confined(20, (3, 8)))
     np.savez_compressed(os.path.join(HERE, "plume64_stats.npz"), **stats64())
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

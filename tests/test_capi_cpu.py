@@ -8,6 +8,7 @@ import re
 import shutil
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -86,3 +87,29 @@ def test_headless_host_program_links_the_shim():
         pytest.skip("host programs not built")
     out = subprocess.run(["ldd", exe], stdout=subprocess.PIPE, text=True).stdout
     assert "libCuSolver.so" in out and "libfluidsolver.so" in out
+
+
+def test_dump_format_round_trip(tmp_path):
+    """fluidsolver_amd.dump: raw float32 files + JSON sidecar, read back with the staggered dims."""
+    from fluidsolver_amd import dump
+
+    class FakeParams:
+        nx, ny, nz, dt, jacobi_iters, scheme, flags = 5, 4, 3, 0.2, 7, 1, 0
+
+    class FakeSolver:
+        params = FakeParams()
+        frame = 11
+
+        def field(self, f):
+            shape = {0: (3, 4, 6), 1: (3, 5, 5), 2: (4, 4, 5)}.get(f, (3, 4, 5))
+            return (np.arange(np.prod(shape), dtype=np.float32) + f).reshape(shape)
+
+    prefix = str(tmp_path / "d")
+    dump.write_dump(FakeSolver(), prefix)
+    meta, fields = dump.read_dump(prefix)
+    assert meta["frame"] == 11 and meta["nx"] == 5 and meta["fields"]["ux"]["dims"] == [6, 4, 3]
+    for f, name in ((0, "ux"), (1, "uy"), (2, "uz"), (3, "rho")):
+        assert np.array_equal(fields[name], FakeSolver().field(f))
+    # x fastest on disk
+    raw = np.fromfile(prefix + "_ux.f32", dtype="<f4")
+    assert raw[1] - raw[0] == 1.0

@@ -46,6 +46,31 @@ def test_oracle_reproduces_64cube_statistics(oracle):
     assert np.array_equal(o.field(3)[32, :, 32], g["s50_rho_centerline"])
 
 
+def check_confined(make, get, step_fn):
+    g = load("plume20_confined.npz")
+    n = int(g["n"])
+    s = make(n, int(g["jacobi_iters"]), float(g["source_y"]), float(g["source_radius"]))
+    done = 0
+    for st in (3, 8):
+        step_fn(s, st - done)
+        done = st
+        for f in (0, 1, 2, 3):
+            assert np.array_equal(get(s, f), g["s%d_%s" % (st, NAMES[f])]), "confined step %d %s" % (st, NAMES[f])
+
+
+def test_oracle_reproduces_confined_fixture(oracle):
+    check_confined(lambda n, k, sy, sr: oracle.Oracle(oracle.default_params(
+        n, n, n, jacobi_iters=k, source_y=sy, source_radius=sr, vort_confine=1)),
+        lambda s, f: s.get(f), lambda s, k: s.step(k))
+
+
+@pytest.mark.gpu
+def test_gpu_matches_confined_fixture(fs):
+    check_confined(lambda n, k, sy, sr: fs.Solver(fs.default_params(
+        n, n, n, jacobi_iters=k, source_y=sy, source_radius=sr, flags=fs.FS_FLAG_VORT_CONFINE)).Initialize(),
+        lambda s, f: s.field(f), lambda s, k: s.step(k))
+
+
 @pytest.mark.gpu
 def test_gpu_matches_small_fixtures(fs):
     def make(n, k, sy, sr):

@@ -329,3 +329,23 @@ def test_jacobi_division_on_hard_inputs(fs, oracle, cfg, monkeypatch):
         bits2 = rng.integers(0, 2 ** 32, shape, dtype=np.uint64).astype(np.uint32)
         bits2[(bits2 >> 23) & 0xFF == 0xFF] &= np.uint32(0x807FFFFF)
         run(p0, bits2.view(np.float32).copy(), "random bit patterns")
+
+
+def test_cpp_bench_dump_matches_python_binding(fs, tmp_path):
+    """fs_bench (C++ over the C ABI) dumps raw fields + a JSON sidecar; the Python binding run with
+    the same parameters must read back identical fields (same library, graph and eager paths)."""
+    import os
+    import subprocess
+    from fluidsolver_amd import dump
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fluidsolver_amd", "bin", "fs_bench")
+    prefix = str(tmp_path / "b24")
+    # 2 warm-up + 3 timed (graph) + 3 profiled (eager) steps
+    subprocess.run([exe, "24", "8", "3", "2", prefix], check=True, stdout=subprocess.PIPE, timeout=120)
+    meta, fields = dump.read_dump(prefix)
+    assert meta["frame"] == 8 and meta["nx"] == 24 and meta["jacobi_iters"] == 8
+    s = fs.Solver(fs.default_params(24, 24, 24, jacobi_iters=8)).Initialize()
+    s.step(8)
+    for f, name in ((fs.FS_UX, "ux"), (fs.FS_UY, "uy"), (fs.FS_UZ, "uz"), (fs.FS_RHO, "rho")):
+        assert np.array_equal(fields[name], s.field(f)), name
+    s.close()
