@@ -65,6 +65,27 @@ def cpu_baseline(iters, sample_n):
     }
 
 
+def measured_copy_bandwidth(torch, device):
+    """Device-to-device copy of 1 GiB (1 read + 1 write per byte) on this GPU, GB/s: what a plain
+    streaming kernel reaches here, to read the spec-peak fractions against."""
+    try:
+        n = 1 << 28
+        x = torch.empty(n, dtype=torch.float32, device="cuda:%d" % device)
+        y = torch.empty_like(x)
+        x.zero_()
+        for _ in range(2):
+            y.copy_(x)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            y.copy_(x)
+        b.record()
+        b.synchronize()
+        return 2.0 * 4.0 * n * 5 / (a.elapsed_time(b) * 1e-3) / 1e9
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def load_pmc_traffic(kernel, workload):
     """HBM bytes per launch from a committed rocprofv3 --pmc pass, if one matches."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -221,6 +242,8 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
+        if world == 1:
+            out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_sample)
         print(json.dumps(out), flush=True)

@@ -26,16 +26,23 @@ Solver& Solver::operator=(Solver&& other) noexcept
 	if (this != &other) {
 		if (handle) fs_destroy(handle);
 		handle = other.handle;
+		jacobi_iters = other.jacobi_iters;
+		vort_confine = other.vort_confine;
+		curl_strength = other.curl_strength;
 		other.handle = nullptr;
 	}
 	return *this;
 }
 
-void Solver::Initialize()
+void Solver::InitializeGrid(int nx, int ny, int nz)
 {
 	fs_params p;
-	check(fs_default_params(&p, Nx, Ny, Nz), "fs_default_params");
+	check(fs_default_params(&p, nx, ny, nz), "fs_default_params");
 	p.jacobi_iters = jacobi_iters;
+	if (vort_confine) p.flags |= FS_FLAG_VORT_CONFINE;
+	p.curl_strength = curl_strength;
+	if (handle) fs_destroy(handle);
+	handle = nullptr;
 	check(fs_create(&p, &handle), "fs_create");
 }
 

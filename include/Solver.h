@@ -5,8 +5,8 @@
  *
  * Same public names and meaning as the reference class (Solver.h:13-44):
  *   Solver(), ~Solver(), Initialize(), Update(), Advect(), Project(), GetDensityField(),
- * plus velocity access, which the reference lacks.  The object holds ONE pointer (the
- * C-ABI handle of include/fluidsolver.h), so constructing it by value on the caller's
+ * plus velocity access, which the reference lacks.  The object holds the C-ABI handle of
+ * include/fluidsolver.h and three settings, so constructing it by value on the caller's
  * stack, as the Renderer does, does not depend on the library's internals.
  *
  * Error behaviour is the reference's (CudaUtility.h:12-23): a failed GPU call prints the
@@ -42,13 +42,19 @@ class SOLVER_API Solver
 public:
 	Solver() {}
 	~Solver();
-	Solver(Solver&& other) noexcept : handle(other.handle) { other.handle = nullptr; }
+	Solver(Solver&& other) noexcept
+	    : handle(other.handle), jacobi_iters(other.jacobi_iters), vort_confine(other.vort_confine),
+	      curl_strength(other.curl_strength) { other.handle = nullptr; }
 	Solver& operator=(Solver&& other) noexcept;
 	Solver(const Solver&) = delete;
 	Solver& operator=(const Solver&) = delete;
 
-	/* allocate + zero all fields, T = T_env (reference Solver.cu:1116-1130) */
-	void Initialize();
+	/* allocate + zero all fields, T = T_env (reference Solver.cu:1116-1130).  Inline on purpose:
+	   the grid is the Nx, Ny, Nz of the translation unit that includes this header, as with the
+	   reference, without rebuilding the library. */
+	void Initialize() { InitializeGrid(Nx, Ny, Nz); }
+	/* new: the same with a run-time grid */
+	void InitializeGrid(int nx, int ny, int nz);
 	/* one simulation step; prints "frame: N" like the reference (Solver.cu:1132-1137) */
 	void Update();
 	/* the two sub-steps the reference also exposes publicly (Solver.h:24,26) */
@@ -61,8 +67,14 @@ public:
 	float* GetVelocityField(int c);
 	/* new: number of Jacobi sweeps per step (reference max_iter, Solver.h:68); call before Initialize */
 	void SetJacobiIterations(int iters) { jacobi_iters = iters; }
+	/* new: vorticity confinement as in the shipped reference build (Solver.cu:13 VORT_CONFINE 1,
+	   curl_strength Solver.h:73), in its defined-behaviour variant (see FS_FLAG_VORT_CONFINE in
+	   fluidsolver.h); off by default; call before Initialize */
+	void SetVorticityConfinement(bool on, float strength = 0.1f) { vort_confine = on; curl_strength = strength; }
 
 private:
 	fs_solver* handle = nullptr;
 	int jacobi_iters = 30;
+	bool vort_confine = false;
+	float curl_strength = 0.1f;
 };
