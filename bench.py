@@ -98,6 +98,37 @@ def load_pmc_traffic(kernel, workload):
         return None
 
 
+def load_valu_instructions(kernel):
+    """Wave-level VALU instructions per launch from the committed rocprofv3 --pmc pass (512^3)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)[kernel]["SQ_INSTS_VALU"])
+    except Exception:
+        return None
+
+
+def stage_rooflines(prof, cells, steps, iters, n):
+    """Per stage: algorithmic bytes per step / device time per step against the HBM peak, and for
+    the gather kernels, whose limiter is instruction issue, the share of the chip's vector-issue
+    rate (1024 SIMDs x one wave instruction per 2 cycles at 2.4 GHz) their committed instruction
+    count amounts to in the time measured now."""
+    out = {}
+    for name, (ms, launches) in prof.items():
+        if ms <= 0 or name not in BYTES_PER_CELL:
+            continue
+        bpc = BYTES_PER_CELL[name] * (iters if name == "jacobi" else 1)
+        gbs = bpc * cells * steps / (ms * 1e-3) / 1e9
+        e = {"ms_per_step": ms / steps, "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+        if name.startswith("advect") and n == 512:
+            insts = load_valu_instructions(name)
+            if insts:
+                e["bound"] = "valu"   # one launch per step: instructions per launch = per step
+                e["valu_issue_frac"] = insts / (ms / steps * 1e-3) / (1024 * 2.4e9 / 2.0)
+        out[name] = e
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,7 +139,7 @@ def main():
     ap.add_argument("--scheme", type=int, default=1)
     ap.add_argument("--naive-jacobi", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--cpu-sample", type=int, default=320)
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl")
     args = ap.parse_args()
 
@@ -229,6 +260,7 @@ def main():
                        "jacobi_sweeps": args.iters, "parallelism": par},
             "step_hbm_frac": step_bytes_per_cell(args.iters) * cells_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "stage_ms_per_step": stage_ms,
+            "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, args.iters, n),
             "roofline": {
                 "kernel": dom,
                 "bound": "hbm",
