@@ -9,7 +9,7 @@
 // components) and one field gather, 8 taps each.  Measured on MI355X the limiter is not HBM but
 // the CU's vector-memory address path (a wave-wide dword load holds it for ~4-7 cycles, a
 // dwordx2 for ~15) and then the VALU.  So the velocity gathers are served from LDS: a workgroup
-// stages the zero-extended velocity brick around its outputs (halo kHalo cells) once, and every
+// stages the zero-extended velocity brick around its outputs (halo 2-3 cells) once, and every
 // gather whose 8 taps fall inside the brick reads LDS (ds_read2_b32 pairs, ~4 cycles per pair);
 // the rare gather that leaves the brick takes the global path below, which returns the same
 // values.  The three velocity components are advected by one kernel so they share the brick.
@@ -174,10 +174,13 @@ struct GlobalSampler {
 // All three arrays use the same index box [org, org + L) per axis; cell (x,y,z) of an array
 // sits at lds[(x-org.x) + (y-org.y)*LX + (z-org.z)*LX*LY].  The image is the zero-extended
 // array: entries outside the array's own extent are 0, like the reference's sample outside.
-template <int BX, int BY, int BZ, int H>
+// HXL / HXR: cells below / above the brick along x, HY and HZ on both sides of y and z; the +1 is
+// the upper tap of the topmost lower-tap index.
+template <int BX, int BY, int BZ, int HXL_, int HXR_, int HY_, int HZ_>
 struct BrickDims {
-    static_assert(BX % 4 == 0 && (H + 1) % 4 == 0, "brick rows are staged as aligned 16-byte quads");
-    static constexpr int LX = BX + 2 * H + 1, LY = BY + 2 * H + 1, LZ = BZ + 2 * H + 1;
+    static_assert(BX % 4 == 0 && (HXL_ + 1) % 4 == 0, "brick rows are staged as aligned 16-byte quads");
+    static constexpr int HXL = HXL_, HXR = HXR_, HY = HY_, HZ = HZ_;
+    static constexpr int LX = BX + HXL + HXR + 1, LY = BY + 2 * HY + 1, LZ = BZ + 2 * HZ + 1;
     static constexpr int LXY = LX * LY, N = LX * LY * LZ;
 };
 
@@ -519,14 +522,22 @@ __device__ __forceinline__ void brick_of_block(const Box& B, int& bx, int& by, i
 // ---------------------------------------------------------------- kernels
 
 // Brick shape of the LDS kernels: 32 x 8 x 4 cells, halo 3, 512 threads (two cells each).
-constexpr int kBX = 32, kBY = 8, kBZ = 4, kHalo = 3, kThreads = 512;
-using Dims = BrickDims<kBX, kBY, kBZ, kHalo>;
+constexpr int kBX = 32, kBY = 8, kBZ = 4, kThreads = 512;
+// Two halo widths.  The narrow brick (2 cells in y and z and above x, 3 below x, which the quad
+// alignment fixes) takes 53 KB, so three workgroups share a CU (six waves per SIMD, <= 80 VGPRs);
+// the wide one (3 cells everywhere) takes 77 KB, two workgroups per CU.  A back-trace stage that
+// leaves the brick in any lane sends its wave through the general path, which is slower but
+// returns the same values, so the choice only matters for speed: the narrow brick is 10-20 %
+// faster as long as displacements stay below about 1.5 cells per stage (|u| dt), the wide one
+// tolerates about 2.5.  FS_ADVECT_BRICK=0 selects the wide brick.
+struct DimsWide : BrickDims<kBX, kBY, kBZ, 3, 3, 3, 3> { static constexpr int kWaves = 4; };
+struct DimsNarrow : BrickDims<kBX, kBY, kBZ, 3, 2, 2, 2> { static constexpr int kWaves = 6; };
 
 // ux, uy, uz advected from the old velocity, all faces with i < B.x0 + B.nx.  Cell (i,j,k) of
 // the box owns face i of ux (if j < ny, k < zend), face j of uy (if k < zend) and face k of uz
 // (if j < ny); the box spans j in [0, ny] and k in [z0, zend].
-template <bool MAC, bool HALO>
-__global__ void __launch_bounds__(kThreads)
+template <class Dims, bool MAC, bool HALO>
+__global__ void __launch_bounds__(kThreads, Dims::kWaves)
 k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* __restrict__ nuz, Vel v,
                       float dt, Box B, int zend, int* halo_flag)
 {
@@ -537,9 +548,9 @@ k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* _
     BrickSampler<Dims> S;
     S.G.init(v);
     S.lds = lds;
-    S.ox = X0 - kHalo;
-    S.oy = Y0 - kHalo;
-    S.oz = Z0 - kHalo;
+    S.ox = X0 - Dims::HXL;
+    S.oy = Y0 - Dims::HY;
+    S.oz = Z0 - Dims::HZ;
     stage_velocity<Dims, kThreads>(lds, v, S.ox, S.oy, S.oz);
     __syncthreads();
 
@@ -560,8 +571,8 @@ k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* _
 
 // T and rho advected with the new velocity; they share one back-trace (same sample position,
 // Solver.cu:381-383 with dir = 0, and same velocity, Solver.cu:1160-1164).
-template <bool MAC, bool HALO>
-__global__ void __launch_bounds__(kThreads)
+template <class Dims, bool MAC, bool HALO>
+__global__ void __launch_bounds__(kThreads, Dims::kWaves)
 k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const float* __restrict__ rho,
                      float* __restrict__ nrho, Vel v, float dt, Box B, int* halo_flag)
 {
@@ -572,9 +583,9 @@ k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const 
     BrickSampler<Dims> S;
     S.G.init(v);
     S.lds = lds;
-    S.ox = X0 - kHalo;
-    S.oy = Y0 - kHalo;
-    S.oz = Z0 - kHalo;
+    S.ox = X0 - Dims::HXL;
+    S.oy = Y0 - Dims::HY;
+    S.oz = Z0 - Dims::HZ;
     stage_velocity<Dims, kThreads>(lds, v, S.ox, S.oy, S.oz);
     __syncthreads();
     const Fld FT = make_fld(T, v.zc, v.pitch, v.plane), FR = make_fld(rho, v.zc, v.pitch, v.plane);
@@ -653,6 +664,12 @@ int path_mask()
     }();
     return v;
 }
+// read per launch: tests run both bricks in one process
+bool narrow_brick()
+{
+    const char* e = getenv("FS_ADVECT_BRICK");
+    return !e || atoi(e) != 0;
+}
 bool use_global_path() { return (path_mask() & 1) != 0; }
 bool scalars_use_lds() { return (path_mask() & 2) == 0; }
 
@@ -711,8 +728,14 @@ void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, fl
     // brick kernel: all faces with i < nx; the ux faces at i = nx go through the global path
     Box B = make_box(kBX, kBY, kBZ, 0, 0, g.z0, g.nx, g.ny + 1, g.nzl + 1);
 #define FS_CALL(M, H)                                                                              \
-    hipLaunchKernelGGL((k_advect_velocity_lds<M, H>), dim3(B.nb), dim3(kThreads), 0, st, ox, oy, oz, v, \
-                       dt, B, zend, halo_flag)
+    do {                                                                                           \
+        if (narrow_brick())                                                                        \
+            hipLaunchKernelGGL((k_advect_velocity_lds<DimsNarrow, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
+                               ox, oy, oz, v, dt, B, zend, halo_flag);                             \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_advect_velocity_lds<DimsWide, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
+                               ox, oy, oz, v, dt, B, zend, halo_flag);                             \
+    } while (0)
     FS_DISPATCH_MH(mac, halo, FS_CALL);
 #undef FS_CALL
     launch_component_global<1>(st, ox, v, dt, mac, halo, g.nx, 0, g.z0, 1, g.ny, g.nzl, true, halo_flag);
@@ -736,8 +759,14 @@ void advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, 
     }
     Box B = make_box(kBX, kBY, kBZ, 0, 0, g.z0, g.nx, g.ny, g.nzl);
 #define FS_CALL(M, H)                                                                             \
-    hipLaunchKernelGGL((k_advect_scalars_lds<M, H>), dim3(B.nb), dim3(kThreads), 0, st, T - zoff, \
-                       nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag)
+    do {                                                                                          \
+        if (narrow_brick())                                                                       \
+            hipLaunchKernelGGL((k_advect_scalars_lds<DimsNarrow, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
+                               T - zoff, nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag); \
+        else                                                                                      \
+            hipLaunchKernelGGL((k_advect_scalars_lds<DimsWide, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
+                               T - zoff, nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag); \
+    } while (0)
     FS_DISPATCH_MH(mac, halo, FS_CALL);
 #undef FS_CALL
 }

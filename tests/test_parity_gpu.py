@@ -115,11 +115,13 @@ def test_jacobi_tile_variants(fs, oracle, dims, cfg, monkeypatch):
         g.close(); o.close()
 
 
+@pytest.mark.parametrize("brick", [0, 1])
 @pytest.mark.parametrize("scheme", [0, 1])
 @pytest.mark.parametrize("dims", [(24, 20, 18), (33, 9, 14)])
-def test_advect_smooth_and_rough(fs, oracle, dims, scheme):
+def test_advect_smooth_and_rough(fs, oracle, dims, scheme, brick, monkeypatch):
     """Advection with a smooth swirl that crosses every wall, and with rough random velocity
-    (back-traces land far outside the box), RK4 and MacCormack."""
+    (back-traces land far outside the box), RK4 and MacCormack, wide and narrow LDS bricks."""
+    monkeypatch.setenv("FS_ADVECT_BRICK", str(brick))
     nx, ny, nz = dims
     for kind in ("smooth", "rough", "zero"):
         g, o = make_pair(fs, oracle, nx, ny, nz, scheme=scheme)
@@ -349,3 +351,22 @@ def test_cpp_bench_dump_matches_python_binding(fs, tmp_path):
     for f, name in ((fs.FS_UX, "ux"), (fs.FS_UY, "uy"), (fs.FS_UZ, "uz"), (fs.FS_RHO, "rho")):
         assert np.array_equal(fields[name], s.field(f)), name
     s.close()
+
+
+@pytest.mark.parametrize("brick", [0, 1])
+def test_advect_displacements_around_the_brick_edge(fs, oracle, brick, monkeypatch):
+    """Uniform velocities whose back-traces end 0.5 ... 3.5 cells away in each direction, so that
+    waves sit on either side of the LDS brick's halo (fast path, general path with LDS taps,
+    general path with global taps) on grids spanning several bricks."""
+    monkeypatch.setenv("FS_ADVECT_BRICK", str(brick))
+    nx, ny, nz = 70, 20, 11
+    for axis in range(3):
+        for speed in (2.5, -2.5, 7.5, -7.5, 12.5, -12.5, 17.5, -17.5):     # dt = 0.2: 0.5 ... 3.5 cells
+            g, o = make_pair(fs, oracle, nx, ny, nz)
+            st = random_fields(nx, ny, nz, seed=200 + axis)
+            for a in range(3):
+                st[a][...] = np.float32(speed if a == axis else 0.3)
+            load_state(g, o, st)
+            g.stage("advect"); o.stage("advect")
+            assert_all_equal(g, o, fields=range(5), what="brick %d axis %d speed %g" % (brick, axis, speed))
+            g.close(); o.close()
