@@ -570,11 +570,14 @@ k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* _
 }
 
 // T and rho advected with the new velocity; they share one back-trace (same sample position,
-// Solver.cu:381-383 with dir = 0, and same velocity, Solver.cu:1160-1164).
-template <class Dims, bool MAC, bool HALO>
+// Solver.cu:381-383 with dir = 0, and same velocity, Solver.cu:1160-1164).  With DIV the kernel
+// also writes the divergence of that velocity (Solver.cu:406-423) for its cells, straight from
+// the staged bricks: the projection that follows then needs no separate pass over the velocity.
+template <class Dims, bool MAC, bool HALO, bool DIV>
 __global__ void __launch_bounds__(kThreads, Dims::kWaves)
 k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const float* __restrict__ rho,
-                     float* __restrict__ nrho, Vel v, float dt, Box B, int* halo_flag)
+                     float* __restrict__ nrho, float* __restrict__ div, Vel v, float dt, Box B,
+                     int* halo_flag)
 {
     __shared__ float lds[3 * Dims::N];
     int bx, by, bz;
@@ -605,6 +608,13 @@ k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const 
         const int o = i + j * v.pitch + k * v.plane;
         nT[o] = gather_global(FT, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
         nrho[o] = gather_global(FR, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+        if (DIV) {
+            const float* q = lds + (i - S.ox) + (j - S.oy) * Dims::LX + (k - S.oz) * Dims::LXY;
+            const float ul = q[0], ur = q[1];
+            const float ubo = q[Dims::N], ut = q[Dims::N + Dims::LX];
+            const float ubh = q[2 * Dims::N], uf = q[2 * Dims::N + Dims::LXY];
+            div[o] = ur + uf + ut - ul - ubh - ubo;          // Solver.cu:420, that order
+        }
     }
     if (HALO && bad) atomicOr(halo_flag, 1);
 }
@@ -741,9 +751,9 @@ void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, fl
     launch_component_global<1>(st, ox, v, dt, mac, halo, g.nx, 0, g.z0, 1, g.ny, g.nzl, true, halo_flag);
 }
 
-void advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
+bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
                     float* nrho, const float* ux, const float* uy, const float* uz, float dt,
-                    int scheme, int* halo_flag)
+                    int scheme, int* halo_flag, float* div)
 {
     Vel v = make_vel(g, ux, uy, uz);
     const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0;
@@ -755,20 +765,27 @@ void advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, 
                        T - zoff, nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag)
         FS_DISPATCH_MH(mac, halo, FS_CALL);
 #undef FS_CALL
-        return;
+        return false;
     }
     Box B = make_box(kBX, kBY, kBZ, 0, 0, g.z0, g.nx, g.ny, g.nzl);
+    float* dv = div ? div - zoff : nullptr;
+#define FS_CALL2(D, M, H, DV)                                                                     \
+    hipLaunchKernelGGL((k_advect_scalars_lds<D, M, H, DV>), dim3(B.nb), dim3(kThreads), 0, st, T - zoff, \
+                       nT - zoff, rho - zoff, nrho - zoff, dv, v, dt, B, halo_flag)
 #define FS_CALL(M, H)                                                                             \
     do {                                                                                          \
-        if (narrow_brick())                                                                       \
-            hipLaunchKernelGGL((k_advect_scalars_lds<DimsNarrow, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
-                               T - zoff, nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag); \
-        else                                                                                      \
-            hipLaunchKernelGGL((k_advect_scalars_lds<DimsWide, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
-                               T - zoff, nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag); \
+        if (narrow_brick()) {                                                                     \
+            if (dv) FS_CALL2(DimsNarrow, M, H, true);                                             \
+            else FS_CALL2(DimsNarrow, M, H, false);                                               \
+        } else {                                                                                  \
+            if (dv) FS_CALL2(DimsWide, M, H, true);                                               \
+            else FS_CALL2(DimsWide, M, H, false);                                                 \
+        }                                                                                         \
     } while (0)
     FS_DISPATCH_MH(mac, halo, FS_CALL);
 #undef FS_CALL
+#undef FS_CALL2
+    return dv != nullptr;
 }
 
 }  // namespace fsk

@@ -59,9 +59,11 @@ void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, fl
                      int* halo_flag);
 int advect_velocity_launches(const FsGrid& g);
 // T and rho share one back-trace (same sample position, Solver.cu:381-383 with dir = 0).
-void advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
+// With div != nullptr the divergence of (ux,uy,uz) over the owned cells is written as well (single
+// slab only); returns whether it was.
+bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
                     float* nrho, const float* ux, const float* uy, const float* uz, float dt,
-                    int scheme, int* halo_flag);
+                    int scheme, int* halo_flag, float* div = nullptr);
 // cell planes [zb, ze) (global indices); the faces uz[ze] must be held locally
 void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, const float* uy,
                 const float* uz, int zb, int ze);

@@ -148,6 +148,7 @@ struct fs_solver {
     char* h_stage[4] = {};            // pinned: send_lo, recv_lo, send_hi, recv_hi
     size_t h_stage_cap = 0;
     bool vel_ghost_ok = false, scal_ghost_ok = false;
+    bool div_fresh = false;           // div holds the divergence of the current velocity
     int p_ghost = 0;                  // valid ghost planes of p on each side
     bool halo_pending = false;        // an exchange is in flight; exchange_wait() orders the compute stream after it
     // captured steps: a step only launches kernels whose arguments are the field pointers and
@@ -758,6 +759,7 @@ int fs_stage_force(fs_solver* s)
     StageScope sc(s, FS_STAGE_FORCE, 1);
     fsk::force_uy(s->st, s->g, s->f.uy, s->f.T, s->prm.dt, s->prm.temperature_env);
     s->vel_ghost_ok = false;
+    s->div_fresh = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -782,13 +784,16 @@ int fs_stage_confine(fs_solver* s)
     fsk::vort_confine(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->vort[0], s->vort[1], s->vort[2],
                       s->prm.curl_strength);
     s->vel_ghost_ok = false;
+    s->div_fresh = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
 
-int fs_stage_advect(fs_solver* s)
+// fuse_div: let the scalar advection also write the divergence of the new velocity (only inside
+// fs_step, where the projection follows at once; a stand-alone fs_stage_advect leaves div alone,
+// as Solver::Advect does)
+static int stage_advect(fs_solver* s, bool fuse_div)
 {
-    if (!s) return fail(FS_ERR_INVALID, "null solver");
     FS_HIP(hipSetDevice(s->device));
     FsFields& f = s->f;
     const float dt = s->prm.dt;
@@ -808,13 +813,23 @@ int fs_stage_advect(fs_solver* s)
     // Solver.cu:1160-1164: T then rho with the NEW (advected, unprojected) velocity
     {
         StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 1);
-        fsk::advect_scalars(s->st, s->g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+        // on one GPU the kernel also leaves the divergence of the new velocity behind, unless the
+        // confinement force is still to change that velocity
+        float* div = (fuse_div && s->world == 1 && !(s->prm.flags & FS_FLAG_VORT_CONFINE)) ? f.div : nullptr;
+        s->div_fresh = fsk::advect_scalars(s->st, s->g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc,
+                                           s->d_flag, div);
     }
     std::swap(f.T, f.nT);
     std::swap(f.rho, f.nrho);
     s->scal_ghost_ok = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
+}
+
+int fs_stage_advect(fs_solver* s)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    return stage_advect(s, false);
 }
 
 int fs_stage_divergence(fs_solver* s)
@@ -832,8 +847,10 @@ int fs_stage_divergence(fs_solver* s)
         if (!g.wall_lo) zb -= ext;
         if (!g.wall_hi) ze += ext;
     }
+    if (s->div_fresh) return FS_OK;   // written by the scalar advection from the same velocity
     StageScope sc(s, FS_STAGE_DIVERGENCE, 1);
     fsk::divergence(s->st, g, s->f.div, s->f.ux, s->f.uy, s->f.uz, zb, ze);
+    s->div_fresh = s->world == 1;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -879,6 +896,7 @@ int fs_stage_gradient(fs_solver* s)
     StageScope sc(s, FS_STAGE_GRADIENT, 1);
     fsk::gradient(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->f.p);
     s->vel_ghost_ok = false;
+    s->div_fresh = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -889,7 +907,7 @@ static int step_eager(fs_solver* s)
     if ((rc = fs_stage_source(s))) return rc;
     if ((rc = fs_stage_force(s))) return rc;
     if ((rc = fs_stage_vorticity(s))) return rc;
-    if ((rc = fs_stage_advect(s))) return rc;
+    if ((rc = stage_advect(s, true))) return rc;
     if ((rc = fs_stage_confine(s))) return rc;
     if ((rc = fs_stage_project(s))) return rc;
     return fs_stage_gradient(s);
@@ -904,9 +922,11 @@ static int step_graph(fs_solver* s)
     for (const fs_solver::StepGraph& g : s->graphs) {
         if (!same_fields(g.before, s->f)) continue;
         FS_HIP(hipGraphLaunch(g.exec, s->st));
+        // host-side state as the eager stages leave it
         s->f = g.after;
         s->prev_held = g.prev_held;
         s->last_sweeps = s->prm.jacobi_iters;
+        s->div_fresh = false;          // the gradient changed the velocity last
         return FS_OK;
     }
     if (s->graphs.size() >= 8) {   // an unusual sequence of stage calls and uploads: start over
@@ -1033,6 +1053,7 @@ int fs_field_upload(fs_solver* s, int field, const float* src)
         return fail(FS_ERR_INVALID, "fs_field_upload: bad argument");
     FS_HIP(hipSetDevice(s->device));
     if (field <= FS_UZ) s->vel_ghost_ok = false;
+    if (field <= FS_UZ || field == FS_DIV) s->div_fresh = false;
     if (field == FS_RHO || field == FS_T) s->scal_ghost_ok = false;
     if (field == FS_P) s->p_ghost = 0;
     return copy_field(s, field, const_cast<float*>(src), false);
@@ -1043,6 +1064,11 @@ int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layout)
     if (!s || !ptr || field < 0 || field >= FS_NUM_FIELDS)
         return fail(FS_ERR_INVALID, "fs_field_device: bad argument");
     *ptr = *field_slot(s, field);
+    // the caller may write through the pointer: forget what was derived from these fields
+    if (field <= FS_UZ || field == FS_DIV) s->div_fresh = false;
+    if (field <= FS_UZ) s->vel_ghost_ok = false;
+    if (field == FS_RHO || field == FS_T) s->scal_ghost_ok = false;
+    if (field == FS_P) s->p_ghost = 0;
     if (layout) {
         layout->dx = s->g.nx + (field == FS_UX);
         layout->dy = s->g.ny + (field == FS_UY);

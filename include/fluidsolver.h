@@ -161,7 +161,10 @@ FS_API const float* fs_field_host(fs_solver* s, int field);
 FS_API size_t fs_field_size(const fs_solver* s, int field);      /* element count, dense */
 /* Upload a dense host array into a field (tests, restart from a dump). */
 FS_API int fs_field_upload(fs_solver* s, int field, const float* src);
-/* Zero-copy access for device-side consumers. *ptr addresses element (0,0,z0). */
+/* Zero-copy access for device-side consumers. *ptr addresses element (0,0,z0).  The pointer is
+   valid until the next call that steps or uploads (buffers are swapped); a consumer that writes
+   through it must call this function again before the next step so that ghost planes and
+   derived fields are refreshed. */
 FS_API int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layout);
 
 /* -- residual: what Mul + Reduce are meant to yield at Solver.cu:1185-1187:

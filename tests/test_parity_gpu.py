@@ -370,3 +370,29 @@ def test_advect_displacements_around_the_brick_edge(fs, oracle, brick, monkeypat
             g.stage("advect"); o.stage("advect")
             assert_all_equal(g, o, fields=range(5), what="brick %d axis %d speed %g" % (brick, axis, speed))
             g.close(); o.close()
+
+
+def test_divergence_fused_into_scalar_advection(fs, oracle):
+    """Inside fs_step (one GPU) the scalar advection also writes the divergence of the advected
+    velocity and the divergence stage is skipped; a stand-alone advect stage leaves div alone,
+    and a divergence stage after anything that changed the velocity or div recomputes it."""
+    nx, ny, nz = 40, 19, 13
+    g, o = make_pair(fs, oracle, nx, ny, nz, jacobi_iters=4, source_y=6.0, source_radius=4.0)
+    st = random_fields(nx, ny, nz, seed=41, vel_scale=2.0)
+    load_state(g, o, st)
+    g.step(2); o.step(2)
+    assert_all_equal(g, o, what="steps with fused divergence")
+    g.stage("advect"); o.stage("advect")
+    assert_all_equal(g, o, what="stand-alone advect")         # div untouched on both sides
+    g.upload(fs.FS_DIV, st[6])
+    g.stage("divergence")
+    assert np.array_equal(g.field(fs.FS_DIV), oracle.divergence(o.get(0), o.get(1), o.get(2)))
+    # a divergence stage marks div as current; a (replayed) step must clear that mark again
+    g.step(); o.step()
+    g.step(); o.step()
+    g.stage("divergence")
+    assert np.array_equal(g.field(fs.FS_DIV), oracle.divergence(o.get(0), o.get(1), o.get(2)))
+    g.stage("force"); o.stage("force")
+    g.stage("divergence")
+    assert np.array_equal(g.field(fs.FS_DIV), oracle.divergence(o.get(0), o.get(1), o.get(2)))
+    g.close(); o.close()
