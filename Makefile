@@ -27,13 +27,16 @@ $(LIBDIR)/fs_jacobi.o: $(CSRC)/fs_jacobi.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
 $(LIBDIR)/fs_vort.o: $(CSRC)/fs_vort.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(LIBDIR)/fs_mgpcg.o: $(CSRC)/fs_mgpcg.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(LIBDIR)/fs_advect.o: $(CSRC)/fs_advect.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/fs_solver.o: $(CSRC)/fs_solver.hip $(CSRC)/fs_kernels.h include/fluidsolver.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(LIBDIR)/fs_kernels.o $(LIBDIR)/fs_jacobi.o $(LIBDIR)/fs_advect.o $(LIBDIR)/fs_vort.o $(LIBDIR)/fs_solver.o
+$(LIB): $(LIBDIR)/fs_kernels.o $(LIBDIR)/fs_jacobi.o $(LIBDIR)/fs_advect.o $(LIBDIR)/fs_vort.o $(LIBDIR)/fs_mgpcg.o $(LIBDIR)/fs_solver.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -Wl,-rpath,/opt/rocm/lib -Wl,-soname,libfluidsolver.so
 
 $(SHIM): $(CSRC)/Solver.cpp include/Solver.h include/fluidsolver.h $(LIB)

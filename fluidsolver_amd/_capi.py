@@ -11,6 +11,7 @@ import numpy as np
 FS_UX, FS_UY, FS_UZ, FS_RHO, FS_T, FS_P, FS_DIV = range(7)
 FIELD_NAMES = {FS_UX: "ux", FS_UY: "uy", FS_UZ: "uz", FS_RHO: "rho", FS_T: "T", FS_P: "p", FS_DIV: "div"}
 FS_SCHEME_RK4, FS_SCHEME_MACCORMACK = 0, 1
+FS_PRESSURE_JACOBI, FS_PRESSURE_MGPCG = 0, 1
 FS_FLAG_NO_GRAPH = 1 << 0
 FS_FLAG_JACOBI_NAIVE = 1 << 1
 FS_FLAG_VORT_CONFINE = 1 << 2
@@ -24,12 +25,12 @@ EXPORTED_SYMBOLS = (
     "fs_stage_divergence",
     "fs_stage_jacobi", "fs_stage_project", "fs_stage_gradient", "fs_density_host",
     "fs_velocity_host", "fs_field_host", "fs_field_size", "fs_field_upload", "fs_field_device",
-    "fs_residual", "fs_last_sweeps", "fs_last_error", "fs_version",
+    "fs_residual", "fs_last_sweeps", "fs_cg_residual", "fs_last_error", "fs_version",
     "fs_profile_enable", "fs_profile_read", "fs_profile_reset",
 )
 
 STAGES = ("source", "force", "advect_velocity", "advect_scalars", "divergence", "jacobi", "gradient",
-          "vorticity", "confine")
+          "vorticity", "confine", "mgpcg")
 
 
 class FsError(RuntimeError):
@@ -55,6 +56,8 @@ class Params(C.Structure):
         ("check_every", C.c_int),
         ("max_sweeps", C.c_int),
         ("curl_strength", C.c_float),
+        ("pressure_solver", C.c_int), ("mg_level", C.c_int), ("init_smooth_steps", C.c_int),
+        ("bottom_smooth_steps", C.c_int), ("iter_precision", C.c_float),
     ]
 
 
@@ -107,6 +110,7 @@ def load_library():
     L.fs_field_upload.argtypes = [vp, C.c_int, _fp]
     L.fs_field_device.argtypes = [vp, C.c_int, C.POINTER(_fp), C.POINTER(Layout)]
     L.fs_residual.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.fs_cg_residual.argtypes = [vp, C.POINTER(C.c_float)]
     L.fs_profile_enable.argtypes = [vp, C.c_int]
     L.fs_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.fs_profile_reset.argtypes = [vp]
@@ -270,3 +274,9 @@ class Solver:
     @property
     def last_sweeps(self):
         return self._L.fs_last_sweeps(self._handle())
+
+    def cg_info(self):
+        """(iterations, r.r) of the last MGPCG solve."""
+        rtr = C.c_float()
+        self._check(self._L.fs_cg_residual(self._handle(), C.byref(rtr)))
+        return self._L.fs_last_sweeps(self._handle()), rtr.value

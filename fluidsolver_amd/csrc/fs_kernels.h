@@ -90,6 +90,17 @@ int jacobi_block();   // sweeps fused per pass
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
 int jacobi_launches(const FsGrid& g, int sweeps, int naive);
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p);
+// Multigrid-preconditioned CG (single slab only); dense work arrays, see fs_mgpcg.hip.
+size_t mg_space(const FsGrid& g, int levels);       // floats in r and in z (all levels)
+int cg_dot_partials();                               // doubles the dot-product scratch must hold
+void cg_init(hipStream_t st, const FsGrid& g, float* r, float* x, const float* div);
+void cg_to_pressure(hipStream_t st, const FsGrid& g, float* p, const float* x);
+void cg_apply_a(hipStream_t st, const FsGrid& g, float* Ap, const float* p);
+void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap, float alpha);
+void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, float beta);
+void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, double* partial, double* out);
+void mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, int levels, int init_smooth_steps,
+                     int bottom_smooth_steps);
 // Vorticity confinement (single slab only).  The three vorticity arrays are dense, vort_elems(g)
 // floats each, zero-filled once by the owner.
 size_t vort_elems(const FsGrid& g);

@@ -127,6 +127,12 @@ struct fs_solver {
     hipStream_t st = nullptr;         // compute stream
     float* pool = nullptr;            // one allocation holding all 13 fields
     float* vort[3] = {};              // dense vorticity arrays (one allocation), FS_FLAG_VORT_CONFINE only
+    // MGPCG work arrays (one allocation): r, z over all levels, p, Ap, x on the fine grid
+    float *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_Ap = nullptr, *cg_x = nullptr;
+    double *cg_partial = nullptr, *cg_out = nullptr;
+    double* h_dot = nullptr;          // pinned
+    bool cg_x_is_pressure = false;    // the reference's member x has become the pressure buffer
+    float cg_rtr = 0.f;
     size_t field_elems = 0;           // floats per field including slack and ghost planes
     size_t origin = 0;                // offset of element (0,0,z0) inside a field
     float* host[FS_NUM_FIELDS] = {};  // pinned dense host copies, allocated on first use
@@ -444,6 +450,67 @@ int run_jacobi(fs_solver* s, int sweeps)
     return FS_OK;
 }
 
+// ---- MGPCG -------------------------------------------------------------------------------------
+
+// dot product as the float the reference's host logic reads (synchronises)
+int cg_dot_sync(fs_solver* s, const float* a, const float* b, float* out)
+{
+    fsk::cg_dot(s->st, s->g, a, b, s->cg_partial, s->cg_out);
+    FS_HIP(hipMemcpyAsync(s->h_dot, s->cg_out, sizeof(double), hipMemcpyDeviceToHost, s->st));
+    FS_HIP(hipStreamSynchronize(s->st));
+    *out = (float)*s->h_dot;
+    return FS_OK;
+}
+
+// Conjugate(f_pressure, f_div), Solver.cu:1226-1297, prints left out
+int run_mgpcg(fs_solver* s)
+{
+    const FsGrid& g = s->g;
+    const fs_params& P = s->prm;
+    StageScope sc(s, FS_STAGE_MGPCG, 1);
+    float *r = s->cg_r, *z = s->cg_z, *p = s->cg_p, *Ap = s->cg_Ap, *x = s->cg_x;
+    auto precondition = [&] {
+        fsk::mg_precondition(s->st, g, r, z, P.mg_level, P.init_smooth_steps, P.bottom_smooth_steps);
+    };
+    int rc;
+    fsk::cg_init(s->st, g, r, x, s->f.div);                       // :1233
+    float rTr = 0.f, old_zTr = 0.f;
+    if ((rc = cg_dot_sync(s, r, r, &rTr))) return rc;             // init_rTr :1237-1239
+    precondition();                                               // :1244
+    fsk::cg_update_p(s->st, g, p, z, 0.f);                        // :1250
+    if ((rc = cg_dot_sync(s, z, r, &old_zTr))) return rc;         // :1252-1254
+    int it = 0;
+    for (; it < P.jacobi_iters; ++it) {
+        fsk::cg_apply_a(s->st, g, Ap, p);                         // :1259
+        float pAp = 0.f;
+        if ((rc = cg_dot_sync(s, p, Ap, &pAp))) return rc;
+        const float alpha = old_zTr / pAp;                        // :1263
+        fsk::cg_update_xr(s->st, g, x, r, p, Ap, alpha);          // :1266
+        if ((rc = cg_dot_sync(s, r, r, &rTr))) return rc;         // :1269-1271
+        if (rTr < P.iter_precision || rTr == 0) {                 // :1275
+            ++it;
+            break;
+        }
+        precondition();                                           // :1279
+        float new_zTr = 0.f;
+        if ((rc = cg_dot_sync(s, z, r, &new_zTr))) return rc;     // :1285-1287
+        const float beta = new_zTr / old_zTr;
+        fsk::cg_update_p(s->st, g, p, z, beta);                   // :1290
+        old_zTr = new_zTr;
+    }
+    s->last_sweeps = it;
+    s->cg_rtr = rTr;
+    // swap(&res, &x) at :1295 exchanges the by-value argument with the member x: the first solve
+    // leaves the pressure field alone and makes x the pressure buffer; from then on the solution
+    // accumulates in the pressure field itself
+    if (s->cg_x_is_pressure) fsk::cg_to_pressure(s->st, g, s->f.p, x);
+    s->cg_x_is_pressure = true;
+    s->prev_held = false;
+    s->p_ghost = 0;
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
 // sum r^2 over the whole grid (all ranks), binary64
 int residual_sync(fs_solver* s, bool previous, double* out)
 {
@@ -485,6 +552,18 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         return fail(FS_ERR_INVALID, "fs_create_slab: rank %d of %d", rank, world);
     if (world > 1 && !unique_id && !fn)
         return fail(FS_ERR_INVALID, "fs_create_slab: neither an RCCL id nor an exchange function");
+    if (p->pressure_solver != FS_PRESSURE_JACOBI && p->pressure_solver != FS_PRESSURE_MGPCG)
+        return fail(FS_ERR_INVALID, "fs_create: unknown pressure_solver %d", p->pressure_solver);
+    if (p->pressure_solver == FS_PRESSURE_MGPCG) {
+        if (world > 1) return fail(FS_ERR_INVALID, "fs_create_slab: FS_PRESSURE_MGPCG is single-GPU only");
+        if (p->mg_level < 1 || p->mg_level > 8 || p->init_smooth_steps < 0 || p->bottom_smooth_steps < 0)
+            return fail(FS_ERR_INVALID, "fs_create: bad multigrid parameters");
+        const int m = 1 << (p->mg_level - 1);
+        if (p->nx % m || p->ny % m || p->nz % m)
+            return fail(FS_ERR_INVALID, "fs_create: FS_PRESSURE_MGPCG needs every dim to be a multiple of %d "
+                                        "(mg_level %d)", m, p->mg_level);
+        if (p->tolerance > 0.f) return fail(FS_ERR_INVALID, "fs_create: convergence mode is for the Jacobi solver");
+    }
     if (world > 1 && (p->flags & FS_FLAG_VORT_CONFINE))
         return fail(FS_ERR_INVALID, "fs_create_slab: FS_FLAG_VORT_CONFINE is single-GPU only (its gathers "
                                     "mix z planes through mismatched strides)");
@@ -562,6 +641,22 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         if (hipMemsetAsync(s->pool, 0, bytes, s->st) != hipSuccess) {
             rc = fail(FS_ERR_HIP, "fs_create: hipMemset failed");
             break;
+        }
+        if (p->pressure_solver == FS_PRESSURE_MGPCG) {
+            const size_t space = fsk::mg_space(g, p->mg_level), n = (size_t)g.nx * g.ny * g.nz;
+            const size_t total = (2 * space + 3 * n) * sizeof(float);
+            e = hipMalloc((void**)&s->cg_r, total);
+            if (e != hipSuccess || hipMemsetAsync(s->cg_r, 0, total, s->st) != hipSuccess ||
+                hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 1) * sizeof(double)) != hipSuccess ||
+                hipHostMalloc((void**)&s->h_dot, sizeof(double)) != hipSuccess) {
+                rc = fail(FS_ERR_HIP, "fs_create: MGPCG work arrays (%zu bytes)", total);
+                break;
+            }
+            s->cg_z = s->cg_r + space;
+            s->cg_p = s->cg_z + space;
+            s->cg_Ap = s->cg_p + n;
+            s->cg_x = s->cg_Ap + n;
+            s->cg_out = s->cg_partial + fsk::cg_dot_partials();
         }
         if (p->flags & FS_FLAG_VORT_CONFINE) {
             const size_t nv = fsk::vort_elems(g);
@@ -671,6 +766,11 @@ int fs_default_params(fs_params* p, int nx, int ny, int nz)
     p->check_every = 8;
     p->max_sweeps = 10000;
     p->curl_strength = 0.1f;   // Solver.h:73
+    p->pressure_solver = FS_PRESSURE_JACOBI;
+    p->mg_level = 4;               // Solver.h:151
+    p->init_smooth_steps = 2;      // Solver.h:153
+    p->bottom_smooth_steps = 50;   // Solver.h:154
+    p->iter_precision = 1e-3f;     // Solver.h:69
     return FS_OK;
 }
 
@@ -700,6 +800,9 @@ int fs_destroy(fs_solver* s)
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->pool) (void)hipFree(s->pool);
     if (s->vort[0]) (void)hipFree(s->vort[0]);
+    if (s->cg_r) (void)hipFree(s->cg_r);
+    if (s->cg_partial) (void)hipFree(s->cg_partial);
+    if (s->h_dot) (void)hipHostFree(s->h_dot);
     if (s->cs) (void)hipStreamDestroy(s->cs);
     if (s->st) (void)hipStreamDestroy(s->st);
     delete s;
@@ -870,6 +973,7 @@ int fs_stage_project(fs_solver* s)
     int rc = fs_stage_divergence(s);
     if (rc) return rc;
     s->last_sweeps = 0;
+    if (s->prm.pressure_solver == FS_PRESSURE_MGPCG) return run_mgpcg(s);
     if (s->prm.tolerance > 0.f) {
         // convergence mode: groups of check_every sweeps until sum r^2 < tolerance
         while (s->last_sweeps < s->prm.max_sweeps) {
@@ -957,8 +1061,9 @@ static int step_graph(fs_solver* s)
 int fs_step(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
+    // (the CG loop reads its scalars on the host, so an MGPCG step cannot be captured)
     const bool graph = s->world == 1 && s->prm.tolerance <= 0.f && !s->profiling &&
-                       !(s->prm.flags & FS_FLAG_NO_GRAPH);
+                       s->prm.pressure_solver == FS_PRESSURE_JACOBI && !(s->prm.flags & FS_FLAG_NO_GRAPH);
     int rc = graph ? step_graph(s) : step_eager(s);
     if (rc) return rc;
     s->frame++;
@@ -985,6 +1090,14 @@ int fs_sync(fs_solver* s)
 int fs_frame(const fs_solver* s) { return s ? s->frame : -1; }
 
 int fs_last_sweeps(const fs_solver* s) { return s ? s->last_sweeps : -1; }
+
+int fs_cg_residual(const fs_solver* s, float* rtr)
+{
+    if (!s || !rtr) return fail(FS_ERR_INVALID, "fs_cg_residual: null argument");
+    if (s->prm.pressure_solver != FS_PRESSURE_MGPCG) return fail(FS_ERR_STATE, "fs_cg_residual: not an MGPCG solver");
+    *rtr = s->cg_rtr;
+    return FS_OK;
+}
 
 size_t fs_field_size(const fs_solver* s, int field)
 {

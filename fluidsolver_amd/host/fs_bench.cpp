@@ -1,5 +1,5 @@
 // fs_bench.cpp -- headless C++ benchmark over the C ABI only (no Python, no torch).
-//   fs_bench [n=256] [sweeps=80] [steps=20] [warmup=5] [dump_prefix|-] [flags=0]
+//   fs_bench [n=256] [sweeps=80] [steps=20] [warmup=5] [dump_prefix|-] [flags=0] [pressure_solver=0]
 // Prints one JSON line: cell-updates/s of `steps` steps and, from a second profiled run of as
 // many steps, the device time per stage.  With dump_prefix, writes
 // the final rho/ux/uy/uz as raw little-endian float32, x fastest (dense reference layout), and
@@ -31,6 +31,7 @@ int main(int argc, char** argv)
 	if (fs_default_params(&p, n, n, n)) die("fs_default_params");
 	p.jacobi_iters = sweeps;
 	p.flags = flags;
+	if (argc > 7) p.pressure_solver = std::atoi(argv[7]);   // FS_PRESSURE_*
 	fs_solver* s = nullptr;
 	if (fs_create(&p, &s)) die("fs_create");
 	if (fs_steps(s, warmup) || fs_sync(s)) die("warmup");
@@ -43,7 +44,7 @@ int main(int argc, char** argv)
 	fs_profile_reset(s);
 	if (fs_steps(s, steps) || fs_sync(s)) die("fs_steps (profiled)");
 	static const char* names[FS_NUM_STAGES] = {"source", "force", "advect_velocity", "advect_scalars",
-	                                           "divergence", "jacobi", "gradient", "vorticity", "confine"};
+	                                           "divergence", "jacobi", "gradient", "vorticity", "confine", "mgpcg"};
 	std::printf("{\"n\": %d, \"sweeps\": %d, \"steps\": %d, \"ms_per_step\": %.4f, \"cell_updates_per_s\": %.6e, "
 	            "\"step_gbs\": %.1f, \"stage_ms_per_step\": {",
 	            n, sweeps, steps, sec / steps * 1e3, (double)n * n * n * steps / sec,

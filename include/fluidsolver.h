@@ -45,6 +45,10 @@ typedef enum fs_status {
 /* field selectors */
 enum { FS_UX = 0, FS_UY = 1, FS_UZ = 2, FS_RHO = 3, FS_T = 4, FS_P = 5, FS_DIV = 6, FS_NUM_FIELDS = 7 };
 
+/* pressure solver (Solver.cu:1178-1192): the Jacobi branch, or the shipped multigrid-
+   preconditioned conjugate gradient (Conjugate :1226-1297, MG_Preconditioner :1312-1366) */
+enum { FS_PRESSURE_JACOBI = 0, FS_PRESSURE_MGPCG = 1 };
+
 /* back-trace scheme of the semi-Lagrangian advection (Solver.cu:11, 393-397) */
 enum { FS_SCHEME_RK4 = 0, FS_SCHEME_MACCORMACK = 1 };
 
@@ -87,6 +91,15 @@ typedef struct fs_params {
     int check_every;
     int max_sweeps;
     float curl_strength;         /* Solver.h:73   0.1, used with FS_FLAG_VORT_CONFINE */
+    /* FS_PRESSURE_MGPCG (single GPU; every dim a multiple of 2^(mg_level-1)): jacobi_iters is the
+       iteration limit, as max_iter is for both branches in the reference (Solver.cu:1256).  The
+       solve follows the reference literally, including that the first solve after creation does
+       not reach the pressure field (the swap at Solver.cu:1295 exchanges a by-value pointer). */
+    int pressure_solver;         /* FS_PRESSURE_*  default FS_PRESSURE_JACOBI */
+    int mg_level;                /* Solver.h:151  4  */
+    int init_smooth_steps;       /* Solver.h:153  2  */
+    int bottom_smooth_steps;     /* Solver.h:154  50 */
+    float iter_precision;        /* Solver.h:69   1e-3, stop when r.r falls below */
 } fs_params;
 
 /* Device-side layout of one field (all fields of a solver share the strides). */
@@ -175,8 +188,10 @@ FS_API int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layo
       i.e. when the last sweep ran on its own (sweep count not a multiple of 4, or
       FS_FLAG_JACOBI_NAIVE), else FS_ERR_STATE. -- */
 FS_API int fs_residual(fs_solver* s, int which, double* out);
-/* sweeps the last fs_step / fs_stage_project actually ran (convergence mode) */
+/* sweeps (Jacobi) or CG iterations (MGPCG) the last fs_step / fs_stage_project actually ran */
 FS_API int fs_last_sweeps(const fs_solver* s);
+/* r.r after the last MGPCG solve (what the reference prints as rTr, Solver.cu:1272) */
+FS_API int fs_cg_residual(const fs_solver* s, float* rtr);
 
 /* -- stage timing (no counterpart in the reference, which only prints fps,
       Renderer/Source/FluidSolver.cpp:179): when enabled, every stage is bracketed by a
@@ -186,7 +201,7 @@ FS_API int fs_last_sweeps(const fs_solver* s);
 enum {
     FS_STAGE_SOURCE = 0, FS_STAGE_FORCE, FS_STAGE_ADVECT_VELOCITY, FS_STAGE_ADVECT_SCALARS,
     FS_STAGE_DIVERGENCE, FS_STAGE_JACOBI, FS_STAGE_GRADIENT, FS_STAGE_VORTICITY, FS_STAGE_CONFINE,
-    FS_NUM_STAGES
+    FS_STAGE_MGPCG, FS_NUM_STAGES
 };
 FS_API int fs_profile_enable(fs_solver* s, int on);
 FS_API int fs_profile_read(fs_solver* s, int stage, double* ms_total, long long* launches);

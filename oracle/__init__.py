@@ -29,6 +29,8 @@ class Params(C.Structure):
         ("source_radius", C.c_float),
         ("rho0", C.c_float), ("temperature0", C.c_float), ("temperature_env", C.c_float),
         ("vort_confine", C.c_int), ("curl_strength", C.c_float),
+        ("pressure_solver", C.c_int), ("mg_level", C.c_int), ("init_smooth_steps", C.c_int),
+        ("bottom_smooth_steps", C.c_int), ("iter_precision", C.c_float),
     ]
 
 
@@ -86,6 +88,24 @@ def lib():
     L.fso_gradient.restype = None
     L.fso_sum_sq.argtypes = [_fp, C.c_size_t]
     L.fso_sum_sq.restype = C.c_double
+    L.fso_last_cg_iters.argtypes = [C.c_void_p]
+    L.fso_last_cg_iters.restype = C.c_int
+    L.fso_last_rtr.argtypes = [C.c_void_p]
+    L.fso_last_rtr.restype = C.c_float
+    L.fso_mg_space.argtypes = [C.c_int] * 4
+    L.fso_mg_space.restype = C.c_size_t
+    L.fso_mg_smooth.argtypes = [_fp, _fp, C.c_size_t] + [C.c_int] * 4
+    L.fso_mg_smooth.restype = None
+    L.fso_mg_restrict.argtypes = [_fp, _fp, C.c_size_t] + [C.c_int] * 3
+    L.fso_mg_restrict.restype = None
+    L.fso_mg_prolongate.argtypes = [_fp, C.c_size_t] + [C.c_int] * 3
+    L.fso_mg_prolongate.restype = None
+    L.fso_mg_precondition.argtypes = [_fp, _fp] + [C.c_int] * 6
+    L.fso_mg_precondition.restype = None
+    L.fso_dot.argtypes = [_fp, _fp, C.c_size_t]
+    L.fso_dot.restype = C.c_float
+    L.fso_apply_a.argtypes = [_fp, _fp] + [C.c_int] * 3
+    L.fso_apply_a.restype = None
     L.fso_vort_size.argtypes = [C.c_int] * 3
     L.fso_vort_size.restype = C.c_size_t
     L.fso_find_vort.argtypes = [_fp] * 6 + [C.c_int] * 3
@@ -168,6 +188,10 @@ class Oracle:
     def residual(self):
         return self._L.fso_residual(self._s)
 
+    def cg_info(self):
+        """(iterations, rTr) of the last MGPCG solve."""
+        return self._L.fso_last_cg_iters(self._s), self._L.fso_last_rtr(self._s)
+
 
 # ---- stateless kernel-level wrappers (arrays are (z, y, x) float32, C-contiguous) ----
 
@@ -242,3 +266,32 @@ def vort_confine(u, vx, vy, vz, dims, dir_, coeff):
     """In-place confinement force on one velocity component (dir_ 1, 2, 3)."""
     nx, ny, nz = dims
     lib().fso_vort_confine(_p(u), _p(vx), _p(vy), _p(vz), nx, ny, nz, dir_, coeff)
+
+
+PRESSURE_JACOBI, PRESSURE_MGPCG = 0, 1
+
+
+def mg_space(nx, ny, nz, levels=4):
+    return lib().fso_mg_space(nx, ny, nz, levels)
+
+
+def mg_precondition(r0, dims, levels=4, init_smooth_steps=2, bottom_smooth_steps=50):
+    """One V-cycle on the level-0 right-hand side r0 (shape (nz, ny, nx)); returns z of level 0."""
+    nx, ny, nz = dims
+    space = mg_space(nx, ny, nz, levels)
+    r = np.zeros(space, np.float32)
+    z = np.zeros(space, np.float32)
+    r[:nx * ny * nz] = np.asarray(r0, np.float32).reshape(-1)
+    lib().fso_mg_precondition(_p(r), _p(z), nx, ny, nz, levels, init_smooth_steps, bottom_smooth_steps)
+    return z[:nx * ny * nz].reshape(nz, ny, nx).copy(), r, z
+
+
+def apply_a(p):
+    nz, ny, nx = p.shape
+    out = np.empty_like(p)
+    lib().fso_apply_a(_p(out), _p(p), nx, ny, nz)
+    return out
+
+
+def dot(a, b):
+    return lib().fso_dot(_p(a.reshape(-1)), _p(b.reshape(-1)), a.size)

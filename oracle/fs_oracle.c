@@ -438,6 +438,137 @@ double fso_sum_sq(const float* r, size_t n)
     return s;
 }
 
+/* ------------------------------------------- multigrid-preconditioned CG (optional) */
+
+/* Solver.cu:44-50 -- sum of the six neighbours, zero outside (that association) */
+static inline float neibor_sum(const float* field, int i, int j, int k, i3 max_pos)
+{
+    return cg_sample(field, mk_i3(i - 1, j, k), max_pos) + cg_sample(field, mk_i3(i + 1, j, k), max_pos)
+         + cg_sample(field, mk_i3(i, j - 1, k), max_pos) + cg_sample(field, mk_i3(i, j + 1, k), max_pos)
+         + cg_sample(field, mk_i3(i, j, k - 1), max_pos) + cg_sample(field, mk_i3(i, j, k + 1), max_pos);
+}
+
+/* Solver.cu:1120-1125: levels are stored one after the other, [level][z][y][x] */
+size_t fso_mg_space(int nx, int ny, int nz, int levels)
+{
+    size_t space = 0, t = (size_t)nx * ny * nz;
+    for (int i = 0; i < levels; ++i) { space += t; t /= 8; }
+    return space;
+}
+
+/* Solver.cu:848-860 -- one colour of red/black Gauss-Seidel on the level at `offset` */
+void fso_mg_smooth(const float* r, float* z, size_t offset, int phase, int dx, int dy, int dz)
+{
+    const i3 max_pos = mk_i3(dx, dy, dz);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < dz; ++k)
+        for (int j = 0; j < dy; ++j)
+            for (int i = 0; i < dx; ++i) {
+                if ((((i + j + k) & 1) != 0) != (phase != 0)) continue;
+                size_t ind = (size_t)i + (size_t)j * dx + (size_t)k * dx * dy;
+                z[offset + ind] = (r[offset + ind] + neibor_sum(z + offset, i, j, k, max_pos)) / 6.f;
+            }
+}
+
+/* Solver.cu:822-834, 862-877 -- the eight phases run one after the other, each adding half the
+ * residual of one child to its parent (the product with the double literal 0.5 and the sum are in
+ * double, narrowed on the store) */
+void fso_mg_restrict(float* r, const float* z, size_t offset, int dx, int dy, int dz)
+{
+    const i3 max_pos = mk_i3(dx, dy, dz);
+    const int cx = dx / 2, cy = dy / 2, cz = dz / 2;
+    const size_t coarse = offset + (size_t)dx * dy * dz;
+    for (int phase = 0; phase < 8; ++phase) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int ck = 0; ck < cz; ++ck)
+            for (int cj = 0; cj < cy; ++cj)
+                for (int ci = 0; ci < cx; ++ci) {
+                    size_t new_ind = (size_t)ci + (size_t)cj * cx + (size_t)ck * cx * cy;
+                    int i = ci * 2 + ((phase & 1) ? 1 : 0);
+                    int j = cj * 2 + ((phase & 2) ? 1 : 0);
+                    int k = ck * 2 + ((phase & 4) ? 1 : 0);
+                    size_t ind = (size_t)i + (size_t)j * dx + (size_t)k * dx * dy;
+                    float res = r[offset + ind] - (6 * z[offset + ind] - neibor_sum(z + offset, i, j, k, max_pos));
+                    r[coarse + new_ind] = (float)((double)r[coarse + new_ind] + (double)res * 0.5);
+                }
+    }
+}
+
+/* Solver.cu:836-846 */
+void fso_mg_prolongate(float* z, size_t offset, int dx, int dy, int dz)
+{
+    const size_t coarse = offset + (size_t)dx * dy * dz;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < dz; ++k)
+        for (int j = 0; j < dy; ++j)
+            for (int i = 0; i < dx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * dx + (size_t)k * dx * dy;
+                size_t new_ind = (size_t)(i >> 1) + (size_t)(j >> 1) * (dx >> 1) +
+                                 (size_t)(k >> 1) * (dx >> 1) * (dy >> 1);
+                z[offset + ind] += z[coarse + new_ind];
+            }
+}
+
+/* Solver.cu:1312-1366 -- one V-cycle: z = M^-1 r (level 0 of r is the input).  The reference
+ * clears z and the coarse levels of r with mg_space/1024 (integer division) blocks of 1024
+ * threads, which leaves a tail uncleared unless the sizes are multiples of 1024 (they are for its
+ * shipped 64x128x64 grid); here everything is cleared. */
+void fso_mg_precondition(float* r, float* z, int nx, int ny, int nz, int levels, int init_smooth_steps,
+                         int bottom_smooth_steps)
+{
+    const size_t space = fso_mg_space(nx, ny, nz, levels), n0 = (size_t)nx * ny * nz;
+    memset(z, 0, space * sizeof(float));
+    memset(r + n0, 0, (space - n0) * sizeof(float));
+    int dx = nx, dy = ny, dz = nz;
+    size_t offset = 0;
+    for (int l = 0; l < levels - 1; ++l) {                                   /* :1330-1343 */
+        for (int i = 0; i < (init_smooth_steps << l); ++i) {
+            fso_mg_smooth(r, z, offset, 0, dx, dy, dz);
+            fso_mg_smooth(r, z, offset, 1, dx, dy, dz);
+        }
+        fso_mg_restrict(r, z, offset, dx, dy, dz);
+        offset += (size_t)dx * dy * dz;
+        dx >>= 1; dy >>= 1; dz >>= 1;
+    }
+    for (int i = 0; i < bottom_smooth_steps; ++i) {                          /* :1346-1350 */
+        fso_mg_smooth(r, z, offset, 0, dx, dy, dz);
+        fso_mg_smooth(r, z, offset, 1, dx, dy, dz);
+    }
+    for (int l = levels - 2; l >= 0; --l) {                                  /* :1352-1365 */
+        dx <<= 1; dy <<= 1; dz <<= 1;
+        offset -= (size_t)dx * dy * dz;
+        fso_mg_prolongate(z, offset, dx, dy, dz);
+        for (int i = 0; i < (init_smooth_steps << l); ++i) {
+            fso_mg_smooth(r, z, offset, 0, dx, dy, dz);
+            fso_mg_smooth(r, z, offset, 1, dx, dy, dz);
+        }
+    }
+}
+
+/* What Mul + Reduce (Solver.cu:231-283, 1212-1224) are meant to yield: the sum of the binary32
+ * products a[i]*b[i].  The reference's tree drops elements at most sizes and races; the defined
+ * target is the plain sum, accumulated in binary64 and narrowed to the float the host reads. */
+float fso_dot(const float* a, const float* b, size_t n)
+{
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += (double)(a[i] * b[i]);
+    return (float)s;
+}
+
+/* Solver.cu:789-799 -- A p = 6 p - neighbours, zero outside the box */
+void fso_apply_a(float* Ap, const float* p, int nx, int ny, int nz)
+{
+    const i3 max_pos = mk_i3(nx, ny, nz);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * ny;
+                float pc = cg_sample(p, mk_i3(i, j, k), max_pos);
+                Ap[ind] = 6.f * pc - neibor_sum(p, i, j, k, max_pos);
+            }
+}
+
 /* --------------------------------------------------------------- whole step */
 
 struct fso_state {
@@ -446,6 +577,12 @@ struct fso_state {
     float *rho, *new_rho, *temperature, *new_temperature;
     float *pressure, *new_pressure, *div, *r;
     float *vortx, *vorty, *vortz;   /* only with vort_confine */
+    /* MGPCG work arrays (Solver.cu:903-907); cg_x is the member `x`, which Conjugate re-points */
+    float *cg_r, *cg_z, *cg_p, *cg_Ap, *cg_x;
+    float* owned[24];               /* every allocation, for fso_destroy (pointers get swapped) */
+    int n_owned;
+    int last_cg_iters;
+    float last_rTr;
     int frame;
 };
 
@@ -465,6 +602,11 @@ void fso_default_params(fso_params* p, int nx, int ny, int nz)
     p->scheme = FSO_SCHEME_MACCORMACK;           /* Solver.cu:11 */
     p->vort_confine = 0;                         /* Solver.cu:13 ships 1; off on the Jacobi hot path */
     p->curl_strength = 0.1f;                     /* Solver.h:73 */
+    p->pressure_solver = FSO_PRESSURE_JACOBI;    /* Solver.cu:1178 ships the MGPCG branch */
+    p->mg_level = 4;                             /* Solver.h:151 */
+    p->init_smooth_steps = 2;                    /* Solver.h:153 */
+    p->bottom_smooth_steps = 50;                 /* Solver.h:154 */
+    p->iter_precision = 1e-3f;                   /* Solver.h:69 */
 }
 
 static float* zalloc(size_t n) { return (float*)calloc(n ? n : 1, sizeof(float)); }
@@ -487,6 +629,20 @@ fso_state* fso_create(const fso_params* p)
         size_t nv = fso_vort_size(p->nx, p->ny, p->nz);
         s->vortx = zalloc(nv); s->vorty = zalloc(nv); s->vortz = zalloc(nv);
     }
+    if (p->pressure_solver == FSO_PRESSURE_MGPCG) {
+        int m = 1 << (p->mg_level - 1);
+        if (p->mg_level < 1 || p->nx % m || p->ny % m || p->nz % m) { fso_destroy(s); return NULL; }
+        size_t space = fso_mg_space(p->nx, p->ny, p->nz, p->mg_level);
+        s->cg_r = zalloc(space); s->cg_z = zalloc(space);                    /* :903-904, 939-940 */
+        s->cg_p = zalloc(n); s->cg_Ap = zalloc(n); s->cg_x = zalloc(n);      /* :905-907 */
+    }
+    {
+        float* all[] = {s->ux, s->uy, s->uz, s->new_ux, s->new_uy, s->new_uz, s->rho, s->new_rho,
+                        s->temperature, s->new_temperature, s->pressure, s->new_pressure, s->div, s->r,
+                        s->vortx, s->vorty, s->vortz, s->cg_r, s->cg_z, s->cg_p, s->cg_Ap, s->cg_x};
+        s->n_owned = (int)(sizeof(all) / sizeof(all[0]));
+        memcpy(s->owned, all, sizeof(all));
+    }
     fso_grid_init(s->temperature, p->temperature_env, p->nx, p->ny, p->nz);
     return s;
 }
@@ -494,10 +650,14 @@ fso_state* fso_create(const fso_params* p)
 void fso_destroy(fso_state* s)
 {
     if (!s) return;
-    free(s->ux); free(s->uy); free(s->uz); free(s->new_ux); free(s->new_uy); free(s->new_uz);
-    free(s->rho); free(s->new_rho); free(s->temperature); free(s->new_temperature);
-    free(s->pressure); free(s->new_pressure); free(s->div); free(s->r);
-    free(s->vortx); free(s->vorty); free(s->vortz);
+    if (s->n_owned) {
+        for (int i = 0; i < s->n_owned; ++i) free(s->owned[i]);
+    } else {   /* creation failed half-way */
+        free(s->ux); free(s->uy); free(s->uz); free(s->new_ux); free(s->new_uy); free(s->new_uz);
+        free(s->rho); free(s->new_rho); free(s->temperature); free(s->new_temperature);
+        free(s->pressure); free(s->new_pressure); free(s->div); free(s->r);
+        free(s->vortx); free(s->vorty); free(s->vortz);
+    }
     free(s);
 }
 
@@ -533,11 +693,53 @@ void fso_stage_advect(fso_state* s)
     swapp(&s->rho, &s->new_rho);
 }
 
-/* Solver.cu:1168-1189, the `#if 0` Jacobi branch without the per-sweep print */
+/* Solver.cu:1226-1297 without the prints.  `res` is the caller's f_pressure BY VALUE: the swap
+ * at :1295 exchanges this local copy with the member x, so the solution reaches the pressure
+ * field only because, from the second call on, member x IS the pressure buffer (the first call
+ * leaves the pressure as it was).  Restated literally. */
+static void conjugate(fso_state* s, float* res, const float* field)
+{
+    const fso_params* p = &s->p;
+    const int nx = p->nx, ny = p->ny, nz = p->nz;
+    const size_t n = (size_t)nx * ny * nz;
+    float *r = s->cg_r, *z = s->cg_z, *cp = s->cg_p, *Ap = s->cg_Ap, *x = s->cg_x;
+    for (size_t i = 0; i < n; ++i) { r[i] = -field[i]; x[i] = 0.f; }         /* InitConjugate :777-786 */
+    float rTr = fso_dot(r, r, n);                                             /* init_rTr :1237-1239 */
+    fso_mg_precondition(r, z, nx, ny, nz, p->mg_level, p->init_smooth_steps, p->bottom_smooth_steps);
+    for (size_t i = 0; i < n; ++i) cp[i] = z[i] + 0 * cp[i];                  /* UpdateP(p, z, 0) :1250 */
+    float old_zTr = fso_dot(z, r, n);                                         /* :1252-1254 */
+    int it = 0;
+    for (; it < p->jacobi_iters; ++it) {                                      /* max_iter :1256 */
+        fso_apply_a(Ap, cp, nx, ny, nz);                                      /* :1259 */
+        float pAp = fso_dot(cp, Ap, n);
+        float alpha = old_zTr / pAp;                                          /* :1263 */
+        for (size_t i = 0; i < n; ++i) {                                      /* UpdateResidual :801-810 */
+            x[i] += alpha * cp[i];
+            r[i] -= alpha * Ap[i];
+        }
+        rTr = fso_dot(r, r, n);                                               /* :1269-1271 */
+        if (rTr < p->iter_precision || rTr == 0) { ++it; break; }            /* :1275 */
+        fso_mg_precondition(r, z, nx, ny, nz, p->mg_level, p->init_smooth_steps, p->bottom_smooth_steps);
+        float new_zTr = fso_dot(z, r, n);                                     /* :1285-1287 */
+        float beta = new_zTr / old_zTr;
+        for (size_t i = 0; i < n; ++i) cp[i] = z[i] + beta * cp[i];           /* UpdateP :812-820 */
+        old_zTr = new_zTr;
+    }
+    s->last_cg_iters = it;
+    s->last_rTr = rTr;
+    { float* t = res; res = s->cg_x; s->cg_x = t; (void)res; }                /* swap(&res, &x) :1295 */
+}
+
+/* Solver.cu:1168-1193: divergence, then the Jacobi branch (`#if 0`, without the per-sweep print)
+ * or the shipped MGPCG branch */
 void fso_stage_project(fso_state* s)
 {
     const fso_params* p = &s->p;
     fso_divergence(s->div, s->ux, s->uy, s->uz, p->nx, p->ny, p->nz);          /* :1176 */
+    if (p->pressure_solver == FSO_PRESSURE_MGPCG) {
+        conjugate(s, s->pressure, s->div);                                     /* :1191 */
+        return;
+    }
     for (int i = 0; i < p->jacobi_iters; ++i) {
         fso_jacobi(s->pressure, s->new_pressure, s->div, s->r, p->nx, p->ny, p->nz); /* :1182 */
         swapp(&s->pressure, &s->new_pressure);                                 /* :1183 */
@@ -620,3 +822,6 @@ double fso_residual(const fso_state* s)
 }
 
 int fso_frame(const fso_state* s) { return s->frame; }
+
+int fso_last_cg_iters(const fso_state* s) { return s->last_cg_iters; }
+float fso_last_rtr(const fso_state* s) { return s->last_rTr; }

@@ -274,3 +274,66 @@ def test_confinement_step_order(oracle):
     for f in range(6):
         assert np.array_equal(a.get(f), b.get(f))
     a.close(); b.close()
+
+
+# ------------------------------------------------------------ MGPCG
+
+def test_apply_a_is_the_dirichlet_laplacian(oracle):
+    """ComputeAp (Solver.cu:789-799): 6p - neighbours with zero outside: constant p = 1 gives 0 in
+    the interior, 1 on faces, 2 on edges, 3 in corners."""
+    p = np.ones((6, 5, 7), np.float32)
+    a = oracle.apply_a(p)
+    assert np.all(a[1:-1, 1:-1, 1:-1] == 0) and a[0, 0, 0] == 3 and a[0, 0, 3] == 2 and a[0, 2, 3] == 1
+
+
+def test_multigrid_levels_and_transfer_operators(oracle):
+    """mg_space (Solver.cu:1120-1125); Restrict adds half of each of the 8 children's residuals
+    (with z = 0 the residual is r); Prolongate injects the parent into its children."""
+    import ctypes as C
+    assert oracle.mg_space(64, 128, 64, 4) == 524288 + 65536 + 8192 + 1024
+    nx, ny, nz = 8, 8, 8
+    n = nx * ny * nz
+    r = np.zeros(oracle.mg_space(nx, ny, nz, 2), np.float32)
+    z = np.zeros_like(r)
+    r[:n] = 1.0
+    L = oracle.lib()
+    L.fso_mg_restrict(oracle._p(r), oracle._p(z), 0, nx, ny, nz)
+    assert np.all(r[n:] == 4.0)                      # 8 children x 0.5
+    z[n:] = np.arange(n // 8, dtype=np.float32)
+    L.fso_mg_prolongate(oracle._p(z), 0, nx, ny, nz)
+    fine = z[:n].reshape(nz, ny, nx)
+    coarse = z[n:].reshape(nz // 2, ny // 2, nx // 2)
+    assert np.array_equal(fine, coarse.repeat(2, 0).repeat(2, 1).repeat(2, 2))
+
+
+def test_red_black_smoother_fixed_point(oracle):
+    """Smooth (Solver.cu:848-860): for r = A z* the exact z* is a fixed point of both colours."""
+    rng = np.random.default_rng(9)
+    zs = rng.integers(-8, 9, (8, 8, 8)).astype(np.float32)        # small integers: exact arithmetic / 6
+    zs *= 6.0
+    r = oracle.apply_a(zs)
+    z = zs.copy().reshape(-1)
+    rr = r.reshape(-1).copy()
+    L = oracle.lib()
+    for phase in (0, 1):
+        L.fso_mg_smooth(oracle._p(rr), oracle._p(z), 0, phase, 8, 8, 8)
+    assert np.array_equal(z.reshape(8, 8, 8), zs)
+
+
+def test_mgpcg_solves_the_system_and_keeps_the_pointer_quirk(oracle):
+    """Conjugate (Solver.cu:1226-1297): r.r falls below iter_precision within a few iterations and
+    A p = -div; the first solve does not reach the pressure field (swap of a by-value pointer at
+    :1295), later ones do."""
+    kw = dict(jacobi_iters=30, source_y=10.0, source_radius=4.0, pressure_solver=oracle.PRESSURE_MGPCG)
+    o = oracle.Oracle(oracle.default_params(16, 24, 16, **kw))
+    o.step()
+    assert not o.get(5).any()                        # frame 0: unprojected
+    it, rtr = o.cg_info()
+    assert 1 <= it <= 10 and rtr < 1e-3
+    o.step()
+    p, div = o.get(5), o.get(6)
+    assert p.any()
+    assert float(np.abs(oracle.apply_a(p) + div).max()) < 5e-3 * float(np.abs(div).max()) + 1e-4
+    o.close()
+    with pytest.raises(MemoryError):                 # dims must be multiples of 2^(levels-1)
+        oracle.Oracle(oracle.default_params(12, 24, 16, **kw))

@@ -396,3 +396,63 @@ def test_divergence_fused_into_scalar_advection(fs, oracle):
     g.stage("divergence")
     assert np.array_equal(g.field(fs.FS_DIV), oracle.divergence(o.get(0), o.get(1), o.get(2)))
     g.close(); o.close()
+
+
+def _mg_pair(fs, oracle, dims, **kw):
+    nx, ny, nz = dims
+    g = fs.Solver(fs.default_params(nx, ny, nz, pressure_solver=fs.FS_PRESSURE_MGPCG, **kw)).Initialize()
+    o = oracle.Oracle(oracle.default_params(nx, ny, nz, pressure_solver=oracle.PRESSURE_MGPCG, **kw))
+    return g, o
+
+
+@pytest.mark.parametrize("dims", [(16, 24, 16), (32, 8, 24), (64, 128, 64)])
+def test_mgpcg_steps_match_oracle(fs, oracle, dims):
+    """FS_PRESSURE_MGPCG (the shipped branch of Solver::Project) against the oracle's literal
+    restatement: same iteration counts, same fields.  Every kernel evaluates the reference
+    expressions; the dot products are binary64 sums of binary32 products on both sides (in a
+    different but fixed order), narrowed to float, so results agree bit for bit unless a sum
+    lands within ~1e-16 of a float rounding boundary -- asserted to 1e-5, exactness reported."""
+    steps = 3 if dims[0] == 64 else 5
+    g, o = _mg_pair(fs, oracle, dims, jacobi_iters=30, source_y=min(10.0, dims[1] / 3.0),
+                    source_radius=min(7.0, min(dims) / 4.0))
+    exact = True
+    for s in range(steps):
+        g.step(); o.step()
+        gi, grtr = g.cg_info()
+        oi, ortr = o.cg_info()
+        assert gi == oi, "step %d: %d vs %d CG iterations" % (s, gi, oi)
+        assert abs(grtr - ortr) <= 1e-4 * max(ortr, 1e-12)
+        for f in range(7):
+            a, b = g.field(f), o.get(f)
+            assert rel_linf(a, b) <= 1e-5, "step %d field %d" % (s, f)
+            exact &= bool(np.array_equal(a, b))
+    if s == 0:
+        assert not g.field(fs.FS_P).any()
+    print("mgpcg %s bit-exact: %s" % (dims, exact))
+    g.close(); o.close()
+
+
+def test_mgpcg_vcycle_and_operator_kernels(fs, oracle):
+    """One project stage from a random velocity field: exercises cg_init, A p, the V-cycle
+    (smoother, restriction, prolongation on 4 levels), the vector updates and the first-solve
+    pointer quirk (pressure untouched), then a second solve (pressure = solution)."""
+    dims = (24, 16, 32)
+    g, o = _mg_pair(fs, oracle, dims, jacobi_iters=30)
+    st = random_fields(*dims, seed=5, vel_scale=1.0)
+    load_state(g, o, st)
+    g.stage("project"); o.stage("project")
+    assert g.cg_info()[0] == o.cg_info()[0] >= 2
+    assert np.array_equal(g.field(fs.FS_P), st[5])         # first solve never reaches the pressure
+    assert_all_equal(g, o, fields=(5, 6), what="first solve")
+    g.stage("project"); o.stage("project")
+    a, b = g.field(fs.FS_P), o.get(5)
+    assert rel_linf(a, b) <= 1e-5 and a.any()
+    g.close(); o.close()
+
+
+def test_mgpcg_rejects_unsuitable_setups(fs):
+    import ctypes as C
+    L = fs.load_library()
+    h = C.c_void_p()
+    p = fs.default_params(20, 16, 16, pressure_solver=fs.FS_PRESSURE_MGPCG)
+    assert L.fs_create(C.byref(p), C.byref(h)) == -1 and b"multiple of 8" in L.fs_last_error()
