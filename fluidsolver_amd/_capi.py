@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "fs_stage_source", "fs_stage_force", "fs_stage_vorticity", "fs_stage_advect", "fs_stage_confine",
     "fs_stage_divergence",
     "fs_stage_jacobi", "fs_stage_project", "fs_stage_gradient", "fs_density_host",
-    "fs_velocity_host", "fs_field_host", "fs_field_size", "fs_field_upload", "fs_field_device",
+    "fs_velocity_host", "fs_field_host", "fs_field_host_begin", "fs_field_host_end", "fs_field_size", "fs_field_upload", "fs_field_device",
     "fs_residual", "fs_last_sweeps", "fs_cg_residual", "fs_last_error", "fs_version",
     "fs_profile_enable", "fs_profile_read", "fs_profile_reset",
 )
@@ -106,6 +106,9 @@ def load_library():
     L.fs_field_host.argtypes = [vp, C.c_int]
     L.fs_field_host.restype = _fp
     L.fs_field_size.argtypes = [vp, C.c_int]
+    L.fs_field_host_begin.argtypes = [vp, C.c_int]
+    L.fs_field_host_end.argtypes = [vp, C.c_int]
+    L.fs_field_host_end.restype = _fp
     L.fs_field_size.restype = C.c_size_t
     L.fs_field_upload.argtypes = [vp, C.c_int, _fp]
     L.fs_field_device.argtypes = [vp, C.c_int, C.POINTER(_fp), C.POINTER(Layout)]
@@ -219,6 +222,17 @@ class Solver:
 
     def stage(self, name, *args):
         self._check(getattr(self._L, "fs_stage_" + name)(self._handle(), *args))
+
+    def field_begin(self, field):
+        """Start an asynchronous read-back of a field (snapshot now, transfer overlaps later steps)."""
+        self._check(self._L.fs_field_host_begin(self._handle(), field))
+
+    def field_end(self, field):
+        ptr = self._L.fs_field_host_end(self._handle(), field)
+        if not ptr:
+            raise FsError(-6, self._L.fs_last_error().decode())
+        p = self.params
+        return np.ctypeslib.as_array(ptr, shape=field_shape(field, p.nx, p.ny, p.nz)).copy()
 
     def field(self, field):
         """Dense host copy (z, y, x) of a field; synchronises."""

@@ -28,6 +28,7 @@ Solver& Solver::operator=(Solver&& other) noexcept
 		handle = other.handle;
 		jacobi_iters = other.jacobi_iters;
 		vort_confine = other.vort_confine;
+		mgpcg = other.mgpcg;
 		curl_strength = other.curl_strength;
 		other.handle = nullptr;
 	}
@@ -41,6 +42,7 @@ void Solver::InitializeGrid(int nx, int ny, int nz)
 	p.jacobi_iters = jacobi_iters;
 	if (vort_confine) p.flags |= FS_FLAG_VORT_CONFINE;
 	p.curl_strength = curl_strength;
+	if (mgpcg) p.pressure_solver = FS_PRESSURE_MGPCG;
 	if (handle) fs_destroy(handle);
 	handle = nullptr;
 	check(fs_create(&p, &handle), "fs_create");

@@ -136,6 +136,11 @@ struct fs_solver {
     size_t field_elems = 0;           // floats per field including slack and ghost planes
     size_t origin = 0;                // offset of element (0,0,z0) inside a field
     float* host[FS_NUM_FIELDS] = {};  // pinned dense host copies, allocated on first use
+    // asynchronous read-back: device snapshot of one field, copy stream, events
+    float* snap = nullptr;
+    hipStream_t copy_st = nullptr;
+    hipEvent_t ev_snap = nullptr, ev_copied = nullptr;
+    int snap_field = -1;              // field whose copy is in flight, -1 = none
     double* d_partial = nullptr;
     double* d_res = nullptr;
     int* d_flag = nullptr;
@@ -800,6 +805,11 @@ int fs_destroy(fs_solver* s)
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->pool) (void)hipFree(s->pool);
     if (s->vort[0]) (void)hipFree(s->vort[0]);
+    if (s->copy_st) (void)hipStreamSynchronize(s->copy_st);
+    if (s->snap) (void)hipFree(s->snap);
+    if (s->ev_snap) (void)hipEventDestroy(s->ev_snap);
+    if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
+    if (s->copy_st) (void)hipStreamDestroy(s->copy_st);
     if (s->cg_r) (void)hipFree(s->cg_r);
     if (s->cg_partial) (void)hipFree(s->cg_partial);
     if (s->h_dot) (void)hipHostFree(s->h_dot);
@@ -1107,11 +1117,13 @@ size_t fs_field_size(const fs_solver* s, int field)
     return (size_t)dx * dy * dz;
 }
 
-static int copy_field(fs_solver* s, int field, float* host, bool to_host)
+// dev = nullptr: the field's current buffer; st = nullptr: the compute stream, synchronised
+static int copy_field(fs_solver* s, int field, float* host, bool to_host, float* dev = nullptr,
+                      hipStream_t st = nullptr)
 {
     int dx, dy, dz;
     field_dims(s, field, dx, dy, dz);
-    float* dev = *field_slot(s, field);
+    if (!dev) dev = *field_slot(s, field);
     hipMemcpy3DParms prm;
     std::memset(&prm, 0, sizeof(prm));
     hipPitchedPtr d = make_hipPitchedPtr(dev, (size_t)s->g.pitch * sizeof(float), (size_t)dx,
@@ -1121,8 +1133,23 @@ static int copy_field(fs_solver* s, int field, float* host, bool to_host)
     prm.dstPtr = to_host ? h : d;
     prm.extent = make_hipExtent((size_t)dx * sizeof(float), (size_t)dy, (size_t)dz);
     prm.kind = to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+    if (st) {
+        FS_HIP(hipMemcpy3DAsync(&prm, st));
+        return FS_OK;
+    }
     FS_HIP(hipMemcpy3DAsync(&prm, s->st));
     FS_HIP(hipStreamSynchronize(s->st));
+    return FS_OK;
+}
+
+static int ensure_host_buffer(fs_solver* s, int field)
+{
+    if (s->host[field]) return FS_OK;
+    size_t bytes = fs_field_size(s, field) * sizeof(float);
+    if (hipHostMalloc((void**)&s->host[field], bytes) != hipSuccess) {
+        s->host[field] = nullptr;
+        return fail(FS_ERR_HIP, "pinned allocation of %zu bytes failed", bytes);
+    }
     return FS_OK;
 }
 
@@ -1136,16 +1163,54 @@ const float* fs_field_host(fs_solver* s, int field)
         fail(FS_ERR_HIP, "hipSetDevice failed");
         return nullptr;
     }
-    if (!s->host[field]) {
-        size_t bytes = fs_field_size(s, field) * sizeof(float);
-        if (hipHostMalloc((void**)&s->host[field], bytes) != hipSuccess) {
-            s->host[field] = nullptr;
-            fail(FS_ERR_HIP, "fs_field_host: pinned allocation of %zu bytes failed", bytes);
-            return nullptr;
-        }
+    if (s->snap_field == field) {   // a copy into this buffer is in flight: finish it first
+        (void)hipEventSynchronize(s->ev_copied);
+        s->snap_field = -1;
     }
+    if (ensure_host_buffer(s, field) != FS_OK) return nullptr;
     if (copy_field(s, field, s->host[field], true) != FS_OK) return nullptr;
     if (check_flag(s) != FS_OK) return nullptr;
+    return s->host[field];
+}
+
+int fs_field_host_begin(fs_solver* s, int field)
+{
+    if (!s || field < 0 || field >= FS_NUM_FIELDS) return fail(FS_ERR_INVALID, "fs_field_host_begin: bad argument");
+    FS_HIP(hipSetDevice(s->device));
+    if (s->snap_field >= 0) return fail(FS_ERR_STATE, "fs_field_host_begin: a read-back is already in flight");
+    int rc = ensure_host_buffer(s, field);
+    if (rc) return rc;
+    if (!s->snap) {
+        FS_HIP(hipMalloc((void**)&s->snap, s->field_elems * sizeof(float)));
+        FS_HIP(hipStreamCreateWithFlags(&s->copy_st, hipStreamNonBlocking));
+        FS_HIP(hipEventCreateWithFlags(&s->ev_snap, hipEventDisableTiming));
+        FS_HIP(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
+    }
+    // device-side snapshot in stream order (0.25 ms at 512^3), so that later steps may overwrite
+    // the field while the snapshot crosses PCIe on the copy stream
+    float* cur = *field_slot(s, field);
+    const ptrdiff_t lead = (ptrdiff_t)s->origin;
+    FS_HIP(hipMemcpyAsync(s->snap, cur - lead, s->field_elems * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+    FS_HIP(hipEventRecord(s->ev_snap, s->st));
+    FS_HIP(hipStreamWaitEvent(s->copy_st, s->ev_snap, 0));
+    rc = copy_field(s, field, s->host[field], true, s->snap + lead, s->copy_st);
+    if (rc) return rc;
+    FS_HIP(hipEventRecord(s->ev_copied, s->copy_st));
+    s->snap_field = field;
+    return FS_OK;
+}
+
+const float* fs_field_host_end(fs_solver* s, int field)
+{
+    if (!s || field < 0 || field >= FS_NUM_FIELDS || s->snap_field != field) {
+        fail(FS_ERR_STATE, "fs_field_host_end: no read-back of this field in flight");
+        return nullptr;
+    }
+    if (hipEventSynchronize(s->ev_copied) != hipSuccess) {
+        fail(FS_ERR_HIP, "fs_field_host_end: hipEventSynchronize failed");
+        return nullptr;
+    }
+    s->snap_field = -1;
     return s->host[field];
 }
 

@@ -5,11 +5,18 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 int main(int argc, char** argv)
 {
 	int frames = argc > 1 ? std::atoi(argv[1]) : 10;
+	// second argument "shipped": the reference's compiled-in configuration (MGPCG + confinement)
+	bool shipped = argc > 2 && std::string(argv[2]) == "shipped";
 	Solver solver = Solver();
+	if (shipped) {
+		solver.SetMultigridSolver(true);
+		solver.SetVorticityConfinement(true);
+	}
 	solver.Initialize();
 	solver.Update();
 	float* rho = solver.GetDensityField();

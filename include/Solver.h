@@ -6,7 +6,7 @@
  * Same public names and meaning as the reference class (Solver.h:13-44):
  *   Solver(), ~Solver(), Initialize(), Update(), Advect(), Project(), GetDensityField(),
  * plus velocity access, which the reference lacks.  The object holds the C-ABI handle of
- * include/fluidsolver.h and three settings, so constructing it by value on the caller's
+ * include/fluidsolver.h and a few settings, so constructing it by value on the caller's
  * stack, as the Renderer does, does not depend on the library's internals.
  *
  * Error behaviour is the reference's (CudaUtility.h:12-23): a failed GPU call prints the
@@ -44,7 +44,7 @@ public:
 	~Solver();
 	Solver(Solver&& other) noexcept
 	    : handle(other.handle), jacobi_iters(other.jacobi_iters), vort_confine(other.vort_confine),
-	      curl_strength(other.curl_strength) { other.handle = nullptr; }
+	      mgpcg(other.mgpcg), curl_strength(other.curl_strength) { other.handle = nullptr; }
 	Solver& operator=(Solver&& other) noexcept;
 	Solver(const Solver&) = delete;
 	Solver& operator=(const Solver&) = delete;
@@ -71,10 +71,14 @@ public:
 	   curl_strength Solver.h:73), in its defined-behaviour variant (see FS_FLAG_VORT_CONFINE in
 	   fluidsolver.h); off by default; call before Initialize */
 	void SetVorticityConfinement(bool on, float strength = 0.1f) { vort_confine = on; curl_strength = strength; }
+	/* new: the shipped reference build solves the pressure with MGPCG (Solver.cu:10, 1190-1192);
+	   false (default) = the Jacobi branch (Solver.cu:1178-1189); call before Initialize */
+	void SetMultigridSolver(bool on) { mgpcg = on; }
 
 private:
 	fs_solver* handle = nullptr;
 	int jacobi_iters = 30;
 	bool vort_confine = false;
+	bool mgpcg = false;
 	float curl_strength = 0.1f;
 };

@@ -172,6 +172,13 @@ FS_API const float* fs_density_host(fs_solver* s);
 FS_API const float* fs_velocity_host(fs_solver* s, int component /* 0,1,2 */);
 FS_API const float* fs_field_host(fs_solver* s, int field);
 FS_API size_t fs_field_size(const fs_solver* s, int field);      /* element count, dense */
+/* Asynchronous form of fs_field_host (no counterpart in the reference, whose blocking copy at
+   Solver.cu:1370 stalls the render loop): _begin takes a device-side snapshot of the field in
+   stream order and starts its copy to the pinned host buffer on a separate stream, so fs_step
+   calls issued afterwards overlap with the transfer; _end waits for it and returns the buffer.
+   One read-back in flight at a time. */
+FS_API int fs_field_host_begin(fs_solver* s, int field);
+FS_API const float* fs_field_host_end(fs_solver* s, int field);
 /* Upload a dense host array into a field (tests, restart from a dump). */
 FS_API int fs_field_upload(fs_solver* s, int field, const float* src);
 /* Zero-copy access for device-side consumers. *ptr addresses element (0,0,z0).  The pointer is
