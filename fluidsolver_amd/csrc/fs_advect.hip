@@ -184,11 +184,10 @@ struct BrickDims {
     static constexpr int LXY = LX * LY, N = LX * LY * LZ;
 };
 
-// One coordinate split on the fast path: integer part, fraction, and the byte offset the
-// integer part contributes to an LDS address.
+// One coordinate split on the fast path: integer part and fraction.
 struct SplitL {
     float f;
-    unsigned off;
+    int i;
 };
 
 template <class D>
@@ -197,6 +196,13 @@ struct BrickSampler {
     GlobalSampler G;
     const float* lds;    // 3 * D::N floats: ux, uy, uz
     int ox, oy, oz;      // global index of LDS element 0 along each axis
+    float lo_x, lo_y, lo_z, hi_x, hi_y, hi_z;   // fast-path bounds, see vel()
+    __device__ __forceinline__ void set_origin(int x, int y, int z)
+    {
+        ox = x; oy = y; oz = z;
+        lo_x = (float)max(x, 0); lo_y = (float)max(y, 0); lo_z = (float)max(z, 0);
+        hi_x = (float)(x + D::LX - 1); hi_y = (float)(y + D::LY - 1); hi_z = (float)(z + D::LZ - 1);
+    }
 
     // ---- general path: literal split, per-gather choice between LDS and global memory ----
     __device__ __forceinline__ float gather(int which, const Fld& F, Axis ax, Axis ay, Axis az,
@@ -232,24 +238,23 @@ struct BrickSampler {
 
     // ---- fast path, taken when it holds for every lane of the wave ----
     // For a coordinate c >= 0 the reference split (Solver.cu:58-82) is ix = floor(c),
-    // fx = c - floor(c): truncation equals floor and the c < -1e-6 fix-up cannot fire.
-    // `scale`/`bias` turn ix into the byte offset of that axis inside the brick; the unsigned
-    // compare against `limit` checks that taps ix and ix+1 are both inside it.
-    __device__ __forceinline__ SplitL split_fast(float c, int scale, int bias, unsigned limit,
-                                                 bool& ok) const
+    // fx = c - floor(c): truncation equals floor, the c < -1e-6 fix-up cannot fire, and
+    // c - floor(c) is exact, which is what v_fract_f32 returns for c >= 0.
+    static __device__ __forceinline__ SplitL split_fast(float c)
     {
-        float fl = floorf(c);
         SplitL s;
-        s.f = c - fl;
-        s.off = (unsigned)(__mul24((int)fl, scale) + bias);
-        ok &= s.off <= limit;
+        s.f = __builtin_amdgcn_fractf(c);
+        s.i = (int)c;
         return s;
     }
-    __device__ __forceinline__ float gather_fast(int which, const SplitL& sx, const SplitL& sy,
+    // cb = byte offset of the array inside the LDS image minus that of the brick origin: the
+    // address of the lowest tap is three multiply-adds away from the integer parts
+    __device__ __forceinline__ float gather_fast(int cb, const SplitL& sx, const SplitL& sy,
                                                  const SplitL& sz) const
     {
-        const char* base = reinterpret_cast<const char*>(lds + which * D::N);
-        const float* q = reinterpret_cast<const float*>(base + (sx.off + sy.off + sz.off));
+        constexpr int SY = 4 * D::LX, SZ = 4 * D::LXY;
+        const int off = __mul24(sz.i, SZ) + (__mul24(sy.i, SY) + ((sx.i << 2) + cb));
+        const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + off);
         float a = q[0], b = q[1], c = q[D::LX], d = q[D::LX + 1];
         const float* q2 = q + D::LXY;
         float e = q2[0], f = q2[1], g = q2[D::LX], h = q2[D::LX + 1];
@@ -259,24 +264,21 @@ struct BrickSampler {
     __device__ __forceinline__ float3 vel(float3 p, int& bad) const
     {
         const float xh = p.x - 0.5f, yh = p.y - 0.5f, zh = p.z - 0.5f;
-        // all six coordinates are >= 0 iff the three shifted ones are
-        bool ok = fminf(fminf(xh, yh), zh) >= 0.f;
-        constexpr int SX = 4, SY = 4 * D::LX, SZ = 4 * D::LXY;
-        constexpr unsigned LIMX = SX * (D::LX - 2), LIMY = SY * (D::LY - 2), LIMZ = SZ * (D::LZ - 2);
-        const int bx = -ox * SX, by = -oy * SY, bz = -oz * SZ;
-        SplitL x0 = split_fast(p.x, SX, bx, LIMX, ok), x5 = split_fast(xh, SX, bx, LIMX, ok);
-        SplitL y0 = split_fast(p.y, SY, by, LIMY, ok), y5 = split_fast(yh, SY, by, LIMY, ok);
-        SplitL z0 = split_fast(p.z, SZ, bz, LIMZ, ok), z5 = split_fast(zh, SZ, bz, LIMZ, ok);
+        // every tap of every gather lies inside the brick, and every coordinate is >= 0, iff the
+        // shifted coordinates are >= max(origin, 0) and the unshifted ones < origin + L - 1
+        // (floor(c) + 1 <= origin + L - 1): six compares against wave-uniform bounds
+        const bool ok = (xh >= lo_x) & (yh >= lo_y) & (zh >= lo_z) & (p.x < hi_x) & (p.y < hi_y) & (p.z < hi_z);
         if (!__all(ok)) return vel_general<HALO>(p, bad);
-        if (HALO) {
-            // ghost-plane check on the plane indices recovered from the offsets
-            int iz5 = (int)(z5.off / (unsigned)SZ) + oz, iz0 = (int)(z0.off / (unsigned)SZ) + oz;
-            bad |= (iz5 < G.zc.chk_lo) | (iz5 > G.zc.chk_hi) | (iz0 < G.zf.chk_lo) | (iz0 > G.zf.chk_hi);
-        }
+        const SplitL x0 = split_fast(p.x), x5 = split_fast(xh);
+        const SplitL y0 = split_fast(p.y), y5 = split_fast(yh);
+        const SplitL z0 = split_fast(p.z), z5 = split_fast(zh);
+        if (HALO) bad |= (z5.i < G.zc.chk_lo) | (z5.i > G.zc.chk_hi) | (z0.i < G.zf.chk_lo) | (z0.i > G.zf.chk_hi);
+        constexpr int SY = 4 * D::LX, SZ = 4 * D::LXY;
+        const int cb = -(4 * ox + SY * oy + SZ * oz);
         float3 u;
-        u.x = gather_fast(0, x0, y5, z5);
-        u.y = gather_fast(1, x5, y0, z5);
-        u.z = gather_fast(2, x5, y5, z0);
+        u.x = gather_fast(cb, x0, y5, z5);
+        u.y = gather_fast(cb + 4 * D::N, x5, y0, z5);
+        u.z = gather_fast(cb + 8 * D::N, x5, y5, z0);
         return u;
     }
 
@@ -548,9 +550,7 @@ k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* _
     BrickSampler<Dims> S;
     S.G.init(v);
     S.lds = lds;
-    S.ox = X0 - Dims::HXL;
-    S.oy = Y0 - Dims::HY;
-    S.oz = Z0 - Dims::HZ;
+    S.set_origin(X0 - Dims::HXL, Y0 - Dims::HY, Z0 - Dims::HZ);
     stage_velocity<Dims, kThreads>(lds, v, S.ox, S.oy, S.oz);
     __syncthreads();
 
@@ -586,9 +586,7 @@ k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const 
     BrickSampler<Dims> S;
     S.G.init(v);
     S.lds = lds;
-    S.ox = X0 - Dims::HXL;
-    S.oy = Y0 - Dims::HY;
-    S.oz = Z0 - Dims::HZ;
+    S.set_origin(X0 - Dims::HXL, Y0 - Dims::HY, Z0 - Dims::HZ);
     stage_velocity<Dims, kThreads>(lds, v, S.ox, S.oy, S.oz);
     __syncthreads();
     const Fld FT = make_fld(T, v.zc, v.pitch, v.plane), FR = make_fld(rho, v.zc, v.pitch, v.plane);
