@@ -172,7 +172,7 @@ struct GlobalSampler {
 
 // LDS brick of the three velocity arrays around an output brick of BX x BY x BZ cells.
 // All three arrays use the same index box [org, org + L) per axis; cell (x,y,z) of an array
-// sits at lds[(x-org.x) + (y-org.y)*LX + (z-org.z)*LX*LY].  The image is the zero-extended
+// sits at lds[(x-org.x)*SX + (y-org.y)*SY + (z-org.z)*SZ].  The image is the zero-extended
 // array: entries outside the array's own extent are 0, like the reference's sample outside.
 // HXL / HXR: cells below / above the brick along x, HY and HZ on both sides of y and z; the +1 is
 // the upper tap of the topmost lower-tap index.
@@ -181,7 +181,13 @@ struct BrickDims {
     static_assert(BX % 4 == 0 && (HXL_ + 1) % 4 == 0, "brick rows are staged as aligned 16-byte quads");
     static constexpr int HXL = HXL_, HXR = HXR_, HY = HY_, HZ = HZ_;
     static constexpr int LX = BX + HXL + HXR + 1, LY = BY + 2 * HY + 1, LZ = BZ + 2 * HZ + 1;
-    static constexpr int LXY = LX * LY, N = LX * LY * LZ;
+    static constexpr int N = LX * LY * LZ;
+    // Element (lx, ly, lz) sits at lx*SX + ly*SY + lz*SZ with z fastest and x slowest: the eight
+    // taps of a gather then span SX + SY + SZ = 127 elements (narrow brick), so one address
+    // register plus the 8-bit offsets of ds_read2_b32 reaches all of them, and lanes that differ
+    // in x (the usual case within a wave) are SX elements apart, an odd number: no bank conflicts.
+    static constexpr int SX = LY * LZ, SY = LZ, SZ = 1;
+    static_assert(SX % 2 == 1, "x stride must be odd to spread lanes over the LDS banks");
 };
 
 // One coordinate split on the fast path: integer part and fraction.
@@ -212,10 +218,10 @@ struct BrickSampler {
         bool in = ((unsigned)lx <= (unsigned)(D::LX - 2)) & ((unsigned)ly <= (unsigned)(D::LY - 2)) &
                   ((unsigned)lz <= (unsigned)(D::LZ - 2));
         if (__builtin_expect(in, 1)) {
-            const float* q = lds + which * D::N + lx + __mul24(ly, D::LX) + __mul24(lz, D::LXY);
-            float a = q[0], b = q[1], c = q[D::LX], d = q[D::LX + 1];
-            const float* q2 = q + D::LXY;
-            float e = q2[0], f = q2[1], g = q2[D::LX], h = q2[D::LX + 1];
+            const float* q = lds + which * D::N + __mul24(lx, D::SX) + __mul24(ly, D::SY) + lz * D::SZ;
+            float a = q[0], b = q[D::SX], c = q[D::SY], d = q[D::SY + D::SX];
+            const float* q2 = q + D::SZ;
+            float e = q2[0], f = q2[D::SX], g = q2[D::SY], h = q2[D::SY + D::SX];
             return trilerp8(a, b, c, d, e, f, g, h, ax.f, ay.f, az.f);
         }
         return gather_global(F, ax, ay, az, dx, dy, zr, G.pitch, G.plane);
@@ -252,12 +258,13 @@ struct BrickSampler {
     __device__ __forceinline__ float gather_fast(int cb, const SplitL& sx, const SplitL& sy,
                                                  const SplitL& sz) const
     {
-        constexpr int SY = 4 * D::LX, SZ = 4 * D::LXY;
-        const int off = __mul24(sz.i, SZ) + (__mul24(sy.i, SY) + ((sx.i << 2) + cb));
+        int off = __mul24(sx.i, 4 * D::SX) + (__mul24(sy.i, 4 * D::SY) + ((sz.i << 2) + cb));
+        // keep the sum in one register: the eight taps are then immediates off one address
+        asm volatile("" : "+v"(off));
         const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + off);
-        float a = q[0], b = q[1], c = q[D::LX], d = q[D::LX + 1];
-        const float* q2 = q + D::LXY;
-        float e = q2[0], f = q2[1], g = q2[D::LX], h = q2[D::LX + 1];
+        float a = q[0], b = q[D::SX], c = q[D::SY], d = q[D::SY + D::SX];
+        const float* q2 = q + D::SZ;
+        float e = q2[0], f = q2[D::SX], g = q2[D::SY], h = q2[D::SY + D::SX];
         return trilerp8(a, b, c, d, e, f, g, h, sx.f, sy.f, sz.f);
     }
     template <bool HALO>
@@ -268,13 +275,13 @@ struct BrickSampler {
         // shifted coordinates are >= max(origin, 0) and the unshifted ones < origin + L - 1
         // (floor(c) + 1 <= origin + L - 1): six compares against wave-uniform bounds
         const bool ok = (xh >= lo_x) & (yh >= lo_y) & (zh >= lo_z) & (p.x < hi_x) & (p.y < hi_y) & (p.z < hi_z);
-        if (!__all(ok)) return vel_general<HALO>(p, bad);
+        // (the ballot of the complement is a scalar test of the compare masks: no vector op)
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) return vel_general<HALO>(p, bad);
         const SplitL x0 = split_fast(p.x), x5 = split_fast(xh);
         const SplitL y0 = split_fast(p.y), y5 = split_fast(yh);
         const SplitL z0 = split_fast(p.z), z5 = split_fast(zh);
         if (HALO) bad |= (z5.i < G.zc.chk_lo) | (z5.i > G.zc.chk_hi) | (z0.i < G.zf.chk_lo) | (z0.i > G.zf.chk_hi);
-        constexpr int SY = 4 * D::LX, SZ = 4 * D::LXY;
-        const int cb = -(4 * ox + SY * oy + SZ * oz);
+        const int cb = -4 * (D::SX * ox + D::SY * oy + D::SZ * oz);
         float3 u;
         u.x = gather_fast(cb, x0, y5, z5);
         u.y = gather_fast(cb + 4 * D::N, x5, y0, z5);
@@ -290,12 +297,12 @@ struct BrickSampler {
     template <bool MX, bool MY, bool MZ>
     static __device__ __forceinline__ float gather_grid(const float* q)
     {
-        auto X = [](const float* r) { return MX ? lerp1(r[0], r[1], 0.5f) : r[0]; };
+        auto X = [](const float* r) { return MX ? lerp1(r[0], r[D::SX], 0.5f) : r[0]; };
         float v00 = X(q);
-        float l1 = MY ? lerp1(v00, X(q + D::LX), 0.5f) : v00;
+        float l1 = MY ? lerp1(v00, X(q + D::SY), 0.5f) : v00;
         if (!MZ) return l1;
-        float v01 = X(q + D::LXY);
-        float l2 = MY ? lerp1(v01, X(q + D::LXY + D::LX), 0.5f) : v01;
+        float v01 = X(q + D::SZ);
+        float l2 = MY ? lerp1(v01, X(q + D::SZ + D::SY), 0.5f) : v01;
         return lerp1(l1, l2, 0.5f);
     }
     // DIR = 0 cell centre, 1/2/3 the x/y/z face of cell (i,j,k); the point is inside the brick.
@@ -304,7 +311,7 @@ struct BrickSampler {
     {
         // sample offsets of the point: 0 on the face axis, .5 elsewhere (Solver.cu:381-383)
         constexpr bool px = DIR != 1, py = DIR != 2, pz = DIR != 3;   // true = offset .5
-        const float* c = lds + (i - ox) + (j - oy) * D::LX + (k - oz) * D::LXY;
+        const float* c = lds + (i - ox) * D::SX + (j - oy) * D::SY + (k - oz) * D::SZ;
         // array a has offset 0 on its own axis and .5 on the others; on an axis where point and
         // array offsets agree the coordinate is the integer index (weight 0); where the point has
         // 0 and the array .5 it is index - .5 (lower tap index-1); where the point has .5 and the
@@ -312,17 +319,17 @@ struct BrickSampler {
         float3 u;
         {   // ux: array offsets (0, .5, .5)
             constexpr bool mx = px, my = !py, mz = !pz;
-            const float* q = c - (my ? D::LX : 0) - (mz ? D::LXY : 0);
+            const float* q = c - (my ? D::SY : 0) - (mz ? D::SZ : 0);
             u.x = gather_grid<mx, my, mz>(q);
         }
         {   // uy: (.5, 0, .5)
             constexpr bool mx = !px, my = py, mz = !pz;
-            const float* q = c + D::N - (mx ? 1 : 0) - (mz ? D::LXY : 0);
+            const float* q = c + D::N - (mx ? D::SX : 0) - (mz ? D::SZ : 0);
             u.y = gather_grid<mx, my, mz>(q);
         }
         {   // uz: (.5, .5, 0)
             constexpr bool mx = !px, my = !py, mz = pz;
-            const float* q = c + 2 * D::N - (mx ? 1 : 0) - (my ? D::LX : 0);
+            const float* q = c + 2 * D::N - (mx ? D::SX : 0) - (my ? D::SY : 0);
             u.z = gather_grid<mx, my, mz>(q);
         }
         return u;
@@ -372,11 +379,12 @@ __device__ __forceinline__ void stage_array(float* dst, const float* __restrict_
         if (e < NQ) {
             int r = e / Q;
             int q = e - r * Q;
-            float* d = dst + r * D::LX + 4 * q - 1;
+            const int lz = r / D::LY, ly = r - lz * D::LY;
+            float* d = dst + (4 * q - 1) * D::SX + ly * D::SY + lz * D::SZ;    // element lx = 4q - 1
             if (q > 0) d[0] = vals[u].x;
-            d[1] = vals[u].y;
-            d[2] = vals[u].z;
-            if (4 * q + 2 < D::LX) d[3] = vals[u].w;
+            d[D::SX] = vals[u].y;
+            d[2 * D::SX] = vals[u].z;
+            if (4 * q + 2 < D::LX) d[3 * D::SX] = vals[u].w;
         }
     }
 }
@@ -607,10 +615,10 @@ k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const 
         nT[o] = gather_global(FT, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
         nrho[o] = gather_global(FR, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
         if (DIV) {
-            const float* q = lds + (i - S.ox) + (j - S.oy) * Dims::LX + (k - S.oz) * Dims::LXY;
-            const float ul = q[0], ur = q[1];
-            const float ubo = q[Dims::N], ut = q[Dims::N + Dims::LX];
-            const float ubh = q[2 * Dims::N], uf = q[2 * Dims::N + Dims::LXY];
+            const float* q = lds + (i - S.ox) * Dims::SX + (j - S.oy) * Dims::SY + (k - S.oz) * Dims::SZ;
+            const float ul = q[0], ur = q[Dims::SX];
+            const float ubo = q[Dims::N], ut = q[Dims::N + Dims::SY];
+            const float ubh = q[2 * Dims::N], uf = q[2 * Dims::N + Dims::SZ];
             div[o] = ur + uf + ut - ul - ubh - ubo;          // Solver.cu:420, that order
         }
     }
