@@ -926,9 +926,9 @@ static int stage_advect(fs_solver* s, bool fuse_div)
     // Solver.cu:1160-1164: T then rho with the NEW (advected, unprojected) velocity
     {
         StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 1);
-        // on one GPU the kernel also leaves the divergence of the new velocity behind, unless the
-        // confinement force is still to change that velocity
-        float* div = (fuse_div && s->world == 1 && !(s->prm.flags & FS_FLAG_VORT_CONFINE)) ? f.div : nullptr;
+        // the kernel also leaves the divergence of the new velocity behind for the owned cells,
+        // unless the confinement force is still to change that velocity
+        float* div = (fuse_div && !(s->prm.flags & FS_FLAG_VORT_CONFINE)) ? f.div : nullptr;
         s->div_fresh = fsk::advect_scalars(s->st, s->g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc,
                                            s->d_flag, div);
     }
@@ -960,10 +960,19 @@ int fs_stage_divergence(fs_solver* s)
         if (!g.wall_lo) zb -= ext;
         if (!g.wall_hi) ze += ext;
     }
-    if (s->div_fresh) return FS_OK;   // written by the scalar advection from the same velocity
+    if (s->div_fresh) {
+        // the owned cells were written by the scalar advection from the same velocity; a slab
+        // still needs the planes beyond it
+        if (s->world == 1) return FS_OK;
+        StageScope sc(s, FS_STAGE_DIVERGENCE, 2);
+        fsk::divergence(s->st, g, s->f.div, s->f.ux, s->f.uy, s->f.uz, zb, g.z0);
+        fsk::divergence(s->st, g, s->f.div, s->f.ux, s->f.uy, s->f.uz, g.z0 + g.nzl, ze);
+        FS_HIP(hipGetLastError());
+        return FS_OK;
+    }
     StageScope sc(s, FS_STAGE_DIVERGENCE, 1);
     fsk::divergence(s->st, g, s->f.div, s->f.ux, s->f.uy, s->f.uz, zb, ze);
-    s->div_fresh = s->world == 1;
+    s->div_fresh = true;
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
