@@ -1,6 +1,6 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun):
-#   tools/profile_round.sh <tag>        e.g. r01
+# Collects the rocprofv3 evidence on the GPU box (run through gpurun):
+#   tools/profile_round.sh <tag>        <tag> names the output files, e.g. r01
 # 1. kernel-trace --stats of the default bench.py run (512^3, 80 sweeps)
 # 2. separate --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass) of the headless C++ bench
 # Output under gpurun_out/prof_<tag>/ ; tools/pmc_to_json.py turns it into profiles/.
