@@ -141,6 +141,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=320)
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = size x size x (size*N) column, strong = size^3 cut into N slabs")
+    ap.add_argument("--tolerance", type=float, default=0.0,
+                    help="> 0: convergence mode, sweep in groups of --check-every until sum r^2 (all ranks) "
+                         "is below it or --iters sweeps are done")
+    ap.add_argument("--check-every", type=int, default=8)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,18 +173,22 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n = args.size
+    nz_total = n * world if args.scaling == "weak" else n
     flags = fs.FS_FLAG_JACOBI_NAIVE if args.naive_jacobi else 0
+    conv = {}
+    if args.tolerance > 0:
+        conv = dict(tolerance=args.tolerance, check_every=args.check_every, max_sweeps=args.iters)
     if world == 1:
         p = fs.default_params(n, n, n, jacobi_iters=args.iters, scheme=args.scheme,
-                              device=device, flags=flags)
+                              device=device, flags=flags, **conv)
         solver = fs.Solver(p).Initialize()
         cells_total = n ** 3
         workload = "%d^3 smoke plume, %d Jacobi sweeps/step, MacCormack, 1 GPU" % (n, args.iters)
         par = "1 GPU"
     else:
         from fluidsolver_amd.slab import SlabSolver
-        p = fs.default_params(n, n, n * world, jacobi_iters=args.iters, scheme=args.scheme,
-                              device=device, flags=flags)
+        p = fs.default_params(n, n, nz_total, jacobi_iters=args.iters, scheme=args.scheme,
+                              device=device, flags=flags, **conv)
         transport = args.transport
         solver = None
         if transport == "rccl":
@@ -198,9 +208,11 @@ def main():
                 transport = "host"
         if solver is None:
             solver = SlabSolver(p, rank, world, transport="host").Initialize()
-        cells_total = n * n * n * world
-        workload = ("%dx%dx%d weak-scaling column, %d Jacobi sweeps/step, MacCormack, z-slabs on %d GPUs, "
-                    "halos over %s" % (n, n, n * world, args.iters, world,
+        cells_total = n * n * nz_total
+        workload = ("%dx%dx%d %s, %d Jacobi sweeps/step, MacCormack, z-slabs on %d GPUs, "
+                    "halos over %s" % (n, n, nz_total,
+                                       "weak-scaling column" if args.scaling == "weak" else "strong scaling",
+                                       args.iters, world,
                                        "RCCL send/recv" if transport == "rccl" else "host buffers + gloo"))
         par = "z-slab x%d" % world
 
@@ -214,8 +226,16 @@ def main():
     barrier()
     solver.profile(True)
     solver.profile_reset()
+    sweeps_done = args.iters * args.steps
     t0 = time.perf_counter()
-    solver.step(args.steps)
+    if args.tolerance > 0:
+        # the sweep count of a step is decided by the residual: count what actually ran
+        sweeps_done = 0
+        for _ in range(args.steps):
+            solver.step(1)
+            sweeps_done += solver.last_sweeps
+    else:
+        solver.step(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = solver.profile_read()
@@ -234,7 +254,7 @@ def main():
         dom = max(prof, key=lambda k: prof[k][0])
         dom_ms, dom_launches = prof[dom]
         if dom == "jacobi":
-            sweeps_per_launch = args.iters * args.steps / max(dom_launches, 1)
+            sweeps_per_launch = sweeps_done / max(dom_launches, 1)
             algo_bytes = BYTES_PER_CELL["jacobi"] * cells_rank * sweeps_per_launch
         else:
             # advect_velocity makes 3 launches per step; its bytes are per stage
@@ -252,15 +272,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (zero initial state, sphere source every step, no RNG)",
-            "config": {"workload": workload, "nx": n, "ny": n, "nz": n * world,
+            "config": {"workload": workload, "nx": n, "ny": n, "nz": nz_total,
                        "jacobi_sweeps": args.iters, "parallelism": par},
-            "step_hbm_frac": step_bytes_per_cell(args.iters) * cells_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "step_hbm_frac": step_bytes_per_cell(sweeps_done / args.steps) * cells_rank / (ms_per_step * 1e-3)
+                             / 1e9 / HBM_PEAK_GBS,
             "stage_ms_per_step": stage_ms,
-            "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, args.iters, n),
+            "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, sweeps_done / args.steps, n),
             "roofline": {
                 "kernel": dom,
                 "bound": "hbm",
@@ -274,6 +295,10 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
+        if args.tolerance > 0:
+            out["config"]["tolerance"] = args.tolerance
+            out["config"]["check_every"] = args.check_every
+            out["config"]["sweeps_per_step_run"] = sweeps_done / args.steps
         if world == 1:
             out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, device)
         if world == 1 and not args.no_cpu_baseline:

@@ -20,6 +20,7 @@
 // 0.54 GB of writes) and runs at the ~5 TB/s this chip sustains for a 2:1 read/write mix.
 #include "fs_kernels.h"
 
+#include <cstdint>
 #include <cstdlib>
 #include <utility>
 
@@ -126,7 +127,16 @@ struct TbLane {
 struct TbRange {
     int n_begin, n_end;  // level-0 planes this workgroup reads: [n_begin, n_end)
     int out_lo, out_hi;  // planes it stores
+    int y0;              // first row of the tile
 };
+
+// What one level computes from the previous one:
+//   kJacobi  a Jacobi sweep of the clamped (Neumann) pressure operator (Solver.cu:426-443)
+//   kRbgs    one colour of a red/black Gauss-Seidel sweep of the zero-outside operator, the
+//            multigrid smoother (Smooth, Solver.cu:848-860): level t updates the cells with
+//            (x + y + z + t - 1) even to (rhs + neibor_sum) / 6 and carries the others over, so a
+//            pass of T levels is T/2 sweeps, red colour first.  `div` holds the right-hand side.
+enum { kJacobi = 0, kRbgs = 1 };
 
 // Level t of march step n: produces plane n-t of level t from planes n-t-1, n-t, n-t+1 of
 // level t-1 (registers), the y-neighbours of plane n-t (LDS, written by the previous step) and div.
@@ -134,37 +144,58 @@ struct TbRange {
 // ramp-up has reached them, or beyond a z wall): those results are never consumed by a plane that
 // is stored, they keep the register and LDS traffic on one fixed schedule, and the step body is
 // free of branches apart from the uniform wall fix-ups.
-template <int T, int NTY, int CPT, int PH, int t>
+template <int KIND, int T, int NTY, int CPT, int PH, int t>
 __device__ __forceinline__ void tb_level(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L, const TbArgs& A,
                                          const TbRange& Z, f4* lcur, const f4* lprv)
 {
     constexpr int H = NTY * CPT;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
     const int k = n - t;                                   // plane this level produces now
-    if (k == A.nz - 1) {                                   // clamped z+1 neighbour at the far wall
+    if (k == A.nz - 1) {                                   // z+1 neighbour at the far wall: clamped / zero
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) tb_plane<t - 1, PH, -t + 1>(R, c) = tb_plane<t - 1, PH, -t>(R, c);
+        for (int c = 0; c < CPT; ++c)
+            tb_plane<t - 1, PH, -t + 1>(R, c) = KIND == kJacobi ? tb_plane<t - 1, PH, -t>(R, c) : zero;
     }
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const f4 ctr = tb_plane<t - 1, PH, -t>(R, c);      // previous level, plane k
-        const f4 pbo = lprv[((t - 1) * H + L.row_dn[c]) * kW4];   // y - 1
-        const f4 pt = lprv[((t - 1) * H + L.row_up[c]) * kW4];    // y + 1
+        f4 pbo = lprv[((t - 1) * H + L.row_dn[c]) * kW4];  // y - 1
+        f4 pt = lprv[((t - 1) * H + L.row_up[c]) * kW4];   // y + 1
         const f4 pbh = tb_plane<t - 1, PH, -t - 1>(R, c);  // z - 1
         const f4 pf = tb_plane<t - 1, PH, -t + 1>(R, c);   // z + 1
         float lft = row_prev(ctr.w), rgt = row_next(ctr.x);
-        if (L.at_left) lft = ctr.x;
-        if (L.at_right) rgt = ctr.w;
         const f4 d = R.dv[wrap(PH - t, 6)][c];
-        const float s0 = lft + ctr.y + pbh.x + pf.x + pbo.x + pt.x - d.x;
-        const float s1 = ctr.x + ctr.z + pbh.y + pf.y + pbo.y + pt.y - d.y;
-        const float s2 = ctr.y + ctr.w + pbh.z + pf.z + pbo.z + pt.z - d.z;
-        const float s3 = ctr.z + rgt + pbh.w + pf.w + pbo.w + pt.w - d.w;
-        const f4 r = {fsk::div6(s0), fsk::div6(s1), fsk::div6(s2), fsk::div6(s3)};
+        f4 r;
+        if constexpr (KIND == kJacobi) {
+            if (L.at_left) lft = ctr.x;
+            if (L.at_right) rgt = ctr.w;
+            const float s0 = lft + ctr.y + pbh.x + pf.x + pbo.x + pt.x - d.x;
+            const float s1 = ctr.x + ctr.z + pbh.y + pf.y + pbo.y + pt.y - d.y;
+            const float s2 = ctr.y + ctr.w + pbh.z + pf.z + pbo.z + pt.z - d.z;
+            const float s3 = ctr.z + rgt + pbh.w + pf.w + pbo.w + pt.w - d.w;
+            r = f4{fsk::div6(s0), fsk::div6(s1), fsk::div6(s2), fsk::div6(s3)};
+        } else {
+            // zero outside the box (cg_sample, Solver.cu:37-42).  A row that is its own y-neighbour
+            // is a wall row or a tile-edge row; the latter is halo whose value is never used.
+            if (L.at_left) lft = 0.f;
+            if (L.at_right) rgt = 0.f;
+            if (L.row_dn[c] == L.row[c]) pbo = zero;
+            if (L.row_up[c] == L.row[c]) pt = zero;
+            // rhs + neibor_sum (Solver.cu:44-50: x-1, x+1, y-1, y+1, z-1, z+1, summed left to right)
+            const float s0 = d.x + (lft + ctr.y + pbo.x + pt.x + pbh.x + pf.x);
+            const float s1 = d.y + (ctr.x + ctr.z + pbo.y + pt.y + pbh.y + pf.y);
+            const float s2 = d.z + (ctr.y + ctr.w + pbo.z + pt.z + pbh.z + pf.z);
+            const float s3 = d.w + (ctr.z + rgt + pbo.w + pt.w + pbh.w + pf.w);
+            // x is a multiple of 4: the colour of this level is cells 0, 2 or cells 1, 3 of the quad
+            const bool even = ((Z.y0 + L.row[c] + k + (t - 1)) & 1) == 0;
+            const float da = fsk::div6(even ? s0 : s1), db = fsk::div6(even ? s2 : s3);
+            r = even ? f4{da, ctr.y, db, ctr.w} : f4{ctr.x, da, ctr.z, db};
+        }
         if constexpr (t < T) {
             tb_plane<t, PH, -t>(R, c) = r;
             lcur[(t * H + L.row[c]) * kW4] = r;
-            // plane 0 of level t: its clamped z-1 neighbour, for level t+1 at the next step
-            if (k == 0) tb_plane<t, PH, -t - 1>(R, c) = r;
+            // plane 0 of level t: its z-1 neighbour (clamped / zero), for level t+1 at the next step
+            if (k == 0) tb_plane<t, PH, -t - 1>(R, c) = KIND == kJacobi ? r : zero;
         } else if (k >= Z.out_lo && k < Z.out_hi) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), plane_rsrc(A.np, k, A), L.st_off[c], 0, 0);
         }
@@ -172,7 +203,7 @@ __device__ __forceinline__ void tb_level(int n, TbRegs<T, CPT>& R, const TbLane<
 }
 
 // One march step; PH == (steps since the first one of this workgroup) mod 6.
-template <int T, int NTY, int CPT, int PH, int... Ts>
+template <int KIND, int T, int NTY, int CPT, int PH, int... Ts>
 __device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L, const TbArgs& A,
                                         const TbRange& Z, f4* lds, std::integer_sequence<int, Ts...>)
 {
@@ -194,13 +225,13 @@ __device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<C
         R.w0[PH % 3][c] = landed;
         lcur[L.row[c] * kW4] = landed;
         // plane 0: the clamped z-1 neighbour is the plane itself
-        if (n == 0) R.w0[wrap(PH - 1, 3)][c] = landed;
+        if (n == 0) R.w0[wrap(PH - 1, 3)][c] = KIND == kJacobi ? landed : f4{0.f, 0.f, 0.f, 0.f};
     }
-    (tb_level<T, NTY, CPT, PH, Ts + 1>(n, R, L, A, Z, lcur, lprv), ...);
+    (tb_level<KIND, T, NTY, CPT, PH, Ts + 1>(n, R, L, A, Z, lcur, lprv), ...);
     __syncthreads();
 }
 
-template <int T, int NTY, int CPT>
+template <int KIND, int T, int NTY, int CPT>
 __global__ void __launch_bounds__(kW4 * NTY)
 k_jacobi_tb(TbArgs A)
 {
@@ -244,6 +275,7 @@ k_jacobi_tb(TbArgs A)
     }
 
     TbRange Z;
+    Z.y0 = y0;
     const bool second = bz >= A.chunks1;
     Z.out_lo = second ? A.zout2_lo + (bz - A.chunks1) * A.lz : A.zout_lo + bz * A.lz;
     Z.out_hi = min(Z.out_lo + A.lz, second ? A.zout2_hi : A.zout_hi);
@@ -269,17 +301,17 @@ k_jacobi_tb(TbArgs A)
     const int last = Z.n_end + T;
     constexpr auto levels = std::make_integer_sequence<int, T>{};
     for (int n = Z.n_begin - 2;;) {
-        tb_step<T, NTY, CPT, 0>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 0>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<T, NTY, CPT, 1>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 1>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<T, NTY, CPT, 2>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 2>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<T, NTY, CPT, 3>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 3>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<T, NTY, CPT, 4>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 4>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<T, NTY, CPT, 5>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 5>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
     }
 }
@@ -344,7 +376,7 @@ int tb_chunk_planes()
     return v;
 }
 
-template <int T, int NTY, int CPT>
+template <int KIND, int T, int NTY, int CPT>
 void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
 {
     constexpr int H = NTY * CPT, BY = H - 2 * T;
@@ -386,10 +418,10 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
     A.nblocks = A.tiles_x * A.tiles_y * chunks;
     A.order = tb_order();
     dim3 grid(A.nblocks), block(kW4, NTY);
-    hipLaunchKernelGGL((k_jacobi_tb<T, NTY, CPT>), grid, block, 0, st, A);
+    hipLaunchKernelGGL((k_jacobi_tb<KIND, T, NTY, CPT>), grid, block, 0, st, A);
 }
 
-template <int T>
+template <int T, int KIND = kJacobi>
 void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
                int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo = 0, int zout2_hi = 0)
 {
@@ -406,8 +438,8 @@ void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const
     A.chunks1 = 0;
     A.lz = 0;
     switch (tb_config(g)) {
-    case 1: launch_tb_cfg<T, 32, 1>(st, g, A); break;
-    default: launch_tb_cfg<T, 64, 1>(st, g, A); break;
+    case 1: launch_tb_cfg<KIND, T, 32, 1>(st, g, A); break;
+    default: launch_tb_cfg<KIND, T, 64, 1>(st, g, A); break;
     }
 }
 
@@ -444,6 +476,22 @@ bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, con
     case 3: launch_tb<3>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi, zout2_lo, zout2_hi); break;
     default: launch_tb<4>(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi, zout2_lo, zout2_hi); break;
     }
+    return true;
+}
+
+// Red/black Gauss-Seidel on a dense nx x ny x nz array (rows unpadded): `phases` half-sweeps (2 or 4,
+// red first) from zin into zout; false if this grid cannot take the blocked kernel.
+bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases)
+{
+    FsGrid g{};
+    g.nx = nx; g.ny = ny; g.nz = nz;
+    g.z0 = 0; g.nzl = nz;
+    g.pitch = nx; g.plane = nx * ny;
+    g.wall_lo = g.wall_hi = 1;
+    const bool aligned = (((uintptr_t)rhs | (uintptr_t)zin | (uintptr_t)zout) & 15u) == 0;
+    if (!can_block(g) || !aligned || (phases != 2 && phases != 4)) return false;
+    if (phases == 4) launch_tb<4, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz);
+    else launch_tb<2, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz);
     return true;
 }
 

@@ -99,8 +99,11 @@ void cg_apply_a(hipStream_t st, const FsGrid& g, float* Ap, const float* p);
 void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap, float alpha);
 void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, float beta);
 void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, double* partial, double* out);
-void mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, int levels, int init_smooth_steps,
-                     int bottom_smooth_steps);
+float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, float* zalt, int levels,
+                       int init_smooth_steps, int bottom_smooth_steps);   // returns z or zalt: the result
+// `phases` (2 or 4) red/black Gauss-Seidel half-sweeps of the zero-outside operator on a dense
+// nx x ny x nz array in one blocked pass, zin -> zout; false if the grid cannot take it
+bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases);
 // Vorticity confinement (single slab only).  The three vorticity arrays are dense, vort_elems(g)
 // floats each, zero-filled once by the owner.
 size_t vort_elems(const FsGrid& g);

@@ -17,6 +17,8 @@
 //     mg_space/1024 whole blocks).
 #include "fs_kernels.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace {
@@ -217,39 +219,64 @@ void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, dou
     hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
 }
 
-// One V-cycle (Solver.cu:1312-1366): z = M^-1 r, level 0 of r is the input.
-void mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, int levels, int init_smooth_steps,
-                     int bottom_smooth_steps)
+// Smallest plane (cells) whose smoothing goes through the temporally blocked kernel; below it a
+// pass of that kernel has too few workgroups to beat four plain launches.  FS_MG_TB_MIN overrides
+// (0 = every level the kernel can take, a huge value = never).
+static long mg_tb_min_plane()
+{
+    if (const char* e = getenv("FS_MG_TB_MIN")) return atol(e);   // read per call: tests switch it
+    return 128L * 128L;
+}
+
+// One V-cycle (Solver.cu:1312-1366): M^-1 r, level 0 of r is the input.  The smoother ping-pongs
+// between z and zalt where it runs blocked, so the result is in either: the return value says
+// which.  zalt needs no clearing (a blocked pass writes every cell of its output).
+float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, float* zalt, int levels,
+                       int init_smooth_steps, int bottom_smooth_steps)
 {
     const size_t space = mg_space(g, levels), n0 = (size_t)g.nx * g.ny * g.nz;
     (void)hipMemsetAsync(z, 0, space * sizeof(float), st);
     if (space > n0) (void)hipMemsetAsync(r + n0, 0, (space - n0) * sizeof(float), st);
+    const long tb_min = mg_tb_min_plane();
+    constexpr int kMaxLevels = 16;
+    float* cur[kMaxLevels];      // array holding the current z of a level
+    float* alt[kMaxLevels];
     Dim3i d{g.nx, g.ny, g.nz};
     size_t offset = 0;
+    int l = 0;
     auto smooth = [&](int steps) {
-        for (int i = 0; i < steps; ++i)
-            for (int phase = 0; phase < 2; ++phase)
-                hipLaunchKernelGGL(k_smooth, dim3(cdiv(cdiv(d.x, 2), 32), cdiv(d.y, 4), d.z), dim3(32, 4), 0, st,
-                                   r + offset, z + offset, phase, d);
+        int phases = 2 * steps;
+        if ((long)d.x * d.y >= tb_min) {
+            while (phases >= 2) {
+                const int take = phases >= 4 ? 4 : 2;
+                if (!rbgs_pass(st, d.x, d.y, d.z, r + offset, cur[l], alt[l], take)) break;
+                float* t = cur[l]; cur[l] = alt[l]; alt[l] = t;
+                phases -= take;
+            }
+        }
+        for (int i = 0; i < phases; ++i)   // red, black, red, ... (phases is even here)
+            hipLaunchKernelGGL(k_smooth, dim3(cdiv(cdiv(d.x, 2), 32), cdiv(d.y, 4), d.z), dim3(32, 4), 0, st,
+                               r + offset, cur[l], i & 1, d);
     };
-    for (int l = 0; l < levels - 1; ++l) {
+    for (; l < levels - 1; ++l) {
+        cur[l] = z + offset; alt[l] = zalt + offset;
         smooth(init_smooth_steps << l);
         const size_t n = (size_t)d.x * d.y * d.z;
         const Dim3i c{d.x / 2, d.y / 2, d.z / 2};
-        hipLaunchKernelGGL(k_restrict, grid3(c, 32, 4), dim3(32, 4), 0, st, r + offset, z + offset, r + offset + n, d);
+        hipLaunchKernelGGL(k_restrict, grid3(c, 32, 4), dim3(32, 4), 0, st, r + offset, cur[l], r + offset + n, d);
         offset += n;
         d = Dim3i{d.x >> 1, d.y >> 1, d.z >> 1};
     }
+    cur[l] = z + offset; alt[l] = zalt + offset;
     smooth(bottom_smooth_steps);
-    for (int l = levels - 2; l >= 0; --l) {
-        const Dim3i c = d;
+    for (l = levels - 2; l >= 0; --l) {
         d = Dim3i{d.x << 1, d.y << 1, d.z << 1};
         const size_t n = (size_t)d.x * d.y * d.z;
         offset -= n;
-        (void)c;
-        hipLaunchKernelGGL(k_prolongate, grid3(d), dim3(64, 4), 0, st, z + offset, z + offset + n, d);
+        hipLaunchKernelGGL(k_prolongate, grid3(d), dim3(64, 4), 0, st, cur[l], cur[l + 1], d);
         smooth(init_smooth_steps << l);
     }
+    return cur[0];
 }
 
 }  // namespace fsk

@@ -128,7 +128,7 @@ struct fs_solver {
     float* pool = nullptr;            // one allocation holding all 13 fields
     float* vort[3] = {};              // dense vorticity arrays (one allocation), FS_FLAG_VORT_CONFINE only
     // MGPCG work arrays (one allocation): r, z over all levels, p, Ap, x on the fine grid
-    float *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_Ap = nullptr, *cg_x = nullptr;
+    float *cg_r = nullptr, *cg_z = nullptr, *cg_zalt = nullptr, *cg_p = nullptr, *cg_Ap = nullptr, *cg_x = nullptr;
     double *cg_partial = nullptr, *cg_out = nullptr;
     double* h_dot = nullptr;          // pinned
     bool cg_x_is_pressure = false;    // the reference's member x has become the pressure buffer
@@ -474,8 +474,13 @@ int run_mgpcg(fs_solver* s)
     const fs_params& P = s->prm;
     StageScope sc(s, FS_STAGE_MGPCG, 1);
     float *r = s->cg_r, *z = s->cg_z, *p = s->cg_p, *Ap = s->cg_Ap, *x = s->cg_x;
-    auto precondition = [&] {
-        fsk::mg_precondition(s->st, g, r, z, P.mg_level, P.init_smooth_steps, P.bottom_smooth_steps);
+    auto precondition = [&] {   // the result may land in either z buffer: follow it
+        float* res = fsk::mg_precondition(s->st, g, r, z, s->cg_zalt, P.mg_level, P.init_smooth_steps,
+                                          P.bottom_smooth_steps);
+        if (res != z) {
+            s->cg_zalt = z;
+            s->cg_z = z = res;
+        }
     };
     int rc;
     fsk::cg_init(s->st, g, r, x, s->f.div);                       // :1233
@@ -649,7 +654,8 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         }
         if (p->pressure_solver == FS_PRESSURE_MGPCG) {
             const size_t space = fsk::mg_space(g, p->mg_level), n = (size_t)g.nx * g.ny * g.nz;
-            const size_t total = (2 * space + 3 * n) * sizeof(float);
+            const size_t space_al = (space + 63) & ~(size_t)63;   // keeps every array 256-byte aligned
+            const size_t total = (3 * space_al + 3 * n) * sizeof(float);
             e = hipMalloc((void**)&s->cg_r, total);
             if (e != hipSuccess || hipMemsetAsync(s->cg_r, 0, total, s->st) != hipSuccess ||
                 hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 1) * sizeof(double)) != hipSuccess ||
@@ -657,8 +663,9 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                 rc = fail(FS_ERR_HIP, "fs_create: MGPCG work arrays (%zu bytes)", total);
                 break;
             }
-            s->cg_z = s->cg_r + space;
-            s->cg_p = s->cg_z + space;
+            s->cg_z = s->cg_r + space_al;
+            s->cg_zalt = s->cg_z + space_al;
+            s->cg_p = s->cg_zalt + space_al;
             s->cg_Ap = s->cg_p + n;
             s->cg_x = s->cg_Ap + n;
             s->cg_out = s->cg_partial + fsk::cg_dot_partials();
