@@ -99,6 +99,9 @@ void cg_apply_a(hipStream_t st, const FsGrid& g, float* Ap, const float* p);
 void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap, float alpha);
 void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, float beta);
 void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, double* partial, double* out);
+void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, double* partial, double* out);
+void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap,
+                      float alpha, double* partial, double* out);
 float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, float* zalt, int levels,
                        int init_smooth_steps, int bottom_smooth_steps);   // returns z or zalt: the result
 // `phases` (2 or 4) red/black Gauss-Seidel half-sweeps of the zero-outside operator on a dense

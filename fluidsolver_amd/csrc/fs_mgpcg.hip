@@ -17,6 +17,7 @@
 //     mg_space/1024 whole blocks).
 #include "fs_kernels.h"
 
+#include <cstdint>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -162,6 +163,131 @@ k_dot_final(const double* __restrict__ partial, int n, double* __restrict__ out)
     if (threadIdx.x == 0) *out = s;
 }
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// k_apply_a and the partial sums of p . Ap in one pass over p; four cells along x per thread
+// (nx % 4 == 0), a fixed strided set of quads per thread.
+__global__ void __launch_bounds__(kDotBlock)
+k_apply_a_dot4(float* __restrict__ Ap, const float* __restrict__ p, Dim3i d, double* __restrict__ partial)
+{
+    __shared__ double sh[kDotBlock / 64];
+    const unsigned nx4 = (unsigned)d.x >> 2, items = nx4 * (unsigned)d.y * (unsigned)d.z;
+    const size_t sy = (size_t)d.x, sz = (size_t)d.x * d.y;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    double s = 0.0;
+    for (unsigned it = blockIdx.x * kDotBlock + threadIdx.x; it < items; it += gridDim.x * kDotBlock) {
+        const unsigned i4 = it % nx4, rest = it / nx4;
+        const int j = (int)(rest % (unsigned)d.y), k = (int)(rest / (unsigned)d.y);
+        const size_t ind = (size_t)4 * i4 + (size_t)j * sy + (size_t)k * sz;
+        const f4 c = *(const f4*)(p + ind);
+        const float lft = i4 > 0 ? p[ind - 1] : 0.f, rgt = i4 + 1 < nx4 ? p[ind + 4] : 0.f;
+        const f4 dn = j > 0 ? *(const f4*)(p + ind - sy) : zero, up = j + 1 < d.y ? *(const f4*)(p + ind + sy) : zero;
+        const f4 bk = k > 0 ? *(const f4*)(p + ind - sz) : zero, fw = k + 1 < d.z ? *(const f4*)(p + ind + sz) : zero;
+        f4 a;
+        a.x = 6.f * c.x - (lft + c.y + dn.x + up.x + bk.x + fw.x);
+        a.y = 6.f * c.y - (c.x + c.z + dn.y + up.y + bk.y + fw.y);
+        a.z = 6.f * c.z - (c.y + c.w + dn.z + up.z + bk.z + fw.z);
+        a.w = 6.f * c.w - (c.z + rgt + dn.w + up.w + bk.w + fw.w);
+        *(f4*)(Ap + ind) = a;
+        s += (double)(c.x * a.x);
+        s += (double)(c.y * a.y);
+        s += (double)(c.z * a.z);
+        s += (double)(c.w * a.w);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// k_update_xr and the partial sums of the new r . r
+__global__ void __launch_bounds__(kDotBlock)
+k_update_xr_dot4(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ p,
+                 const float* __restrict__ Ap, float alpha, unsigned items, double* __restrict__ partial)
+{
+    __shared__ double sh[kDotBlock / 64];
+    double s = 0.0;
+    for (unsigned it = blockIdx.x * kDotBlock + threadIdx.x; it < items; it += gridDim.x * kDotBlock) {
+        const size_t ind = (size_t)4 * it;
+        const f4 pv = *(const f4*)(p + ind), av = *(const f4*)(Ap + ind);
+        f4 xv = *(const f4*)(x + ind), rv = *(const f4*)(r + ind);
+        xv += alpha * pv;
+        rv -= alpha * av;
+        *(f4*)(x + ind) = xv;
+        *(f4*)(r + ind) = rv;
+        s += (double)(rv.x * rv.x);
+        s += (double)(rv.y * rv.y);
+        s += (double)(rv.z * rv.z);
+        s += (double)(rv.w * rv.w);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// k_dot_partial with 16-byte loads (n % 4 == 0)
+__global__ void __launch_bounds__(kDotBlock)
+k_dot_partial4(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ partial, unsigned items)
+{
+    __shared__ double sh[kDotBlock / 64];
+    double s = 0.0;
+    for (unsigned it = blockIdx.x * kDotBlock + threadIdx.x; it < items; it += gridDim.x * kDotBlock) {
+        const f4 av = *(const f4*)(a + (size_t)4 * it), bv = *(const f4*)(b + (size_t)4 * it);
+        s += (double)(av.x * bv.x);
+        s += (double)(av.y * bv.y);
+        s += (double)(av.z * bv.z);
+        s += (double)(av.w * bv.w);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// k_restrict with the rows of a coarse cell's 4 x 4 x 4 neighbourhood loaded once: 24 loads
+// instead of 64 (nx % 2 == 0 keeps the 8-byte loads aligned)
+__global__ void k_restrict2(const float* __restrict__ r, const float* __restrict__ z, float* __restrict__ rc, Dim3i d)
+{
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x, cj = blockIdx.y * blockDim.y + threadIdx.y, ck = blockIdx.z;
+    const int cx = d.x / 2, cy = d.y / 2;
+    if (ci >= cx || cj >= cy) return;
+    const size_t sy = (size_t)d.x, sz = (size_t)d.x * d.y;
+    const int i = 2 * ci, j = 2 * cj, k = 2 * ck;
+    const size_t base = (size_t)i + (size_t)j * sy + (size_t)k * sz;
+    const f2 zero = {0.f, 0.f};
+    // z of the children rows (y, z in {0,1}): cells i-1 .. i+2
+    f2 zc[2][2];
+    float zl[2][2], zr[2][2];
+    f2 zyl[2], zyh[2], zzl[2], zzh[2], rr[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const size_t o = base + a * sy + b * sz;
+            zc[b][a] = *(const f2*)(z + o);
+            rr[b][a] = *(const f2*)(r + o);
+            zl[b][a] = i > 0 ? z[o - 1] : 0.f;
+            zr[b][a] = i + 2 < d.x ? z[o + 2] : 0.f;
+        }
+        zyl[b] = j > 0 ? *(const f2*)(z + base + b * sz - sy) : zero;           // row y = j-1
+        zyh[b] = j + 2 < d.y ? *(const f2*)(z + base + b * sz + 2 * sy) : zero;  // row y = j+2
+        zzl[b] = k > 0 ? *(const f2*)(z + base + b * sy - sz) : zero;           // plane z = k-1, row y = j+b
+        zzh[b] = k + 2 < d.z ? *(const f2*)(z + base + b * sy + 2 * sz) : zero;  // plane z = k+2
+    }
+    const size_t cind = (size_t)ci + (size_t)cj * cx + (size_t)ck * cx * cy;
+    float acc = rc[cind];
+#pragma unroll
+    for (int phase = 0; phase < 8; ++phase) {
+        const int a = phase & 1, b = (phase >> 1) & 1, c = (phase >> 2) & 1;   // child offsets in x, y, z
+        const float zc0 = a ? zc[c][b].y : zc[c][b].x;
+        const float xm = a ? zc[c][b].x : zl[c][b], xp = a ? zr[c][b] : zc[c][b].y;
+        const f2 rowm = b ? zc[c][0] : zyl[c], rowp = b ? zyh[c] : zc[c][1];
+        const f2 plm = c ? zc[0][b] : zzl[b], plp = c ? zzh[b] : zc[1][b];
+        const float ym = a ? rowm.y : rowm.x, yp = a ? rowp.y : rowp.x;
+        const float km = a ? plm.y : plm.x, kp = a ? plp.y : plp.x;
+        const float rv = a ? rr[c][b].y : rr[c][b].x;
+        const float res = rv - (6 * zc0 - (xm + xp + ym + yp + km + kp));
+        acc = (float)((double)acc + (double)res * 0.5);
+    }
+    rc[cind] = acc;
+}
+
 dim3 grid3(Dim3i d, int tx = 64, int ty = 4) { return dim3(cdiv(d.x, tx), cdiv(d.y, ty), d.z); }
 
 }  // namespace
@@ -204,6 +330,42 @@ void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const flo
     hipLaunchKernelGGL(k_update_xr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, r, p, Ap, alpha, n);
 }
 
+static int dot_blocks(size_t work)
+{
+    const size_t b = (work + kDotBlock - 1) / kDotBlock;
+    return (int)(b < (size_t)cg_dot_partials() ? b : (size_t)cg_dot_partials());
+}
+
+// Ap = A p and *out = p . Ap
+void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, double* partial, double* out)
+{
+    if (g.nx % 4 != 0) {
+        cg_apply_a(st, g, Ap, p);
+        cg_dot(st, g, p, Ap, partial, out);
+        return;
+    }
+    const Dim3i d{g.nx, g.ny, g.nz};
+    const int blocks = dot_blocks((size_t)g.nx / 4 * g.ny * g.nz);
+    hipLaunchKernelGGL(k_apply_a_dot4, dim3(blocks), dim3(kDotBlock), 0, st, Ap, p, d, partial);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
+}
+
+// x += alpha p, r -= alpha Ap and *out = r . r of the new r
+void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap,
+                      float alpha, double* partial, double* out)
+{
+    const size_t n = (size_t)g.nx * g.ny * g.nz;
+    if (n % 4 != 0) {
+        cg_update_xr(st, g, x, r, p, Ap, alpha);
+        cg_dot(st, g, r, r, partial, out);
+        return;
+    }
+    const int blocks = dot_blocks(n / 4);
+    hipLaunchKernelGGL(k_update_xr_dot4, dim3(blocks), dim3(kDotBlock), 0, st, x, r, p, Ap, alpha, (unsigned)(n / 4),
+                       partial);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
+}
+
 void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, float beta)
 {
     const size_t n = (size_t)g.nx * g.ny * g.nz;
@@ -213,9 +375,10 @@ void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, floa
 void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, double* partial, double* out)
 {
     const size_t n = (size_t)g.nx * g.ny * g.nz;
-    const int blocks = (int)((n + kDotBlock - 1) / kDotBlock < (size_t)cg_dot_partials() ? (n + kDotBlock - 1) / kDotBlock
-                                                                                     : (size_t)cg_dot_partials());
-    hipLaunchKernelGGL(k_dot_partial, dim3(blocks), dim3(kDotBlock), 0, st, a, b, partial, n);
+    const bool quads = n % 4 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15u) == 0;
+    const int blocks = dot_blocks(quads ? n / 4 : n);
+    if (quads) hipLaunchKernelGGL(k_dot_partial4, dim3(blocks), dim3(kDotBlock), 0, st, a, b, partial, (unsigned)(n / 4));
+    else hipLaunchKernelGGL(k_dot_partial, dim3(blocks), dim3(kDotBlock), 0, st, a, b, partial, n);
     hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
 }
 
@@ -263,7 +426,11 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
         smooth(init_smooth_steps << l);
         const size_t n = (size_t)d.x * d.y * d.z;
         const Dim3i c{d.x / 2, d.y / 2, d.z / 2};
-        hipLaunchKernelGGL(k_restrict, grid3(c, 32, 4), dim3(32, 4), 0, st, r + offset, cur[l], r + offset + n, d);
+        // (the level offsets are even, so 8-byte loads are aligned whenever nx is even)
+        if (d.x % 2 == 0 && d.y % 2 == 0 && d.z % 2 == 0 && (n & 1) == 0 && (offset & 1) == 0)
+            hipLaunchKernelGGL(k_restrict2, grid3(c, 32, 4), dim3(32, 4), 0, st, r + offset, cur[l], r + offset + n, d);
+        else
+            hipLaunchKernelGGL(k_restrict, grid3(c, 32, 4), dim3(32, 4), 0, st, r + offset, cur[l], r + offset + n, d);
         offset += n;
         d = Dim3i{d.x >> 1, d.y >> 1, d.z >> 1};
     }

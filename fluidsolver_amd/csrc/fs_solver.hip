@@ -458,9 +458,17 @@ int run_jacobi(fs_solver* s, int sweeps)
 // ---- MGPCG -------------------------------------------------------------------------------------
 
 // dot product as the float the reference's host logic reads (synchronises)
+int cg_read_sum(fs_solver* s, float* out);
+
 int cg_dot_sync(fs_solver* s, const float* a, const float* b, float* out)
 {
     fsk::cg_dot(s->st, s->g, a, b, s->cg_partial, s->cg_out);
+    return cg_read_sum(s, out);
+}
+
+// the sum a fused kernel pair has left in cg_out, as the float the host logic reads (synchronises)
+int cg_read_sum(fs_solver* s, float* out)
+{
     FS_HIP(hipMemcpyAsync(s->h_dot, s->cg_out, sizeof(double), hipMemcpyDeviceToHost, s->st));
     FS_HIP(hipStreamSynchronize(s->st));
     *out = (float)*s->h_dot;
@@ -491,12 +499,12 @@ int run_mgpcg(fs_solver* s)
     if ((rc = cg_dot_sync(s, z, r, &old_zTr))) return rc;         // :1252-1254
     int it = 0;
     for (; it < P.jacobi_iters; ++it) {
-        fsk::cg_apply_a(s->st, g, Ap, p);                         // :1259
+        fsk::cg_apply_a_dot(s->st, g, Ap, p, s->cg_partial, s->cg_out);   // :1259 and the products of :1261
         float pAp = 0.f;
-        if ((rc = cg_dot_sync(s, p, Ap, &pAp))) return rc;
+        if ((rc = cg_read_sum(s, &pAp))) return rc;
         const float alpha = old_zTr / pAp;                        // :1263
-        fsk::cg_update_xr(s->st, g, x, r, p, Ap, alpha);          // :1266
-        if ((rc = cg_dot_sync(s, r, r, &rTr))) return rc;         // :1269-1271
+        fsk::cg_update_xr_dot(s->st, g, x, r, p, Ap, alpha, s->cg_partial, s->cg_out);   // :1266, :1269-1271
+        if ((rc = cg_read_sum(s, &rTr))) return rc;
         if (rTr < P.iter_precision || rTr == 0) {                 // :1275
             ++it;
             break;
