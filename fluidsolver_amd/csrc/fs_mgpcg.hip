@@ -97,6 +97,39 @@ __global__ void k_smooth(const float* __restrict__ r, float* z, int phase, Dim3i
     z[ind] = fsk::div6(r[ind] + neibor_sum(z, i, j, k, d));
 }
 
+// All colours of `steps` sweeps of a level that fits one workgroup's LDS (z and the right-hand side,
+// at most kSmoothLdsCells cells): the coarse levels of a V-cycle are a chain of tiny dependent
+// launches otherwise.  Same expression and colour order as k_smooth.
+constexpr int kSmoothLdsCells = 8192;
+constexpr int kSmoothLdsThreads = 1024;
+
+__global__ void __launch_bounds__(kSmoothLdsThreads)
+k_smooth_lds(const float* __restrict__ r, float* __restrict__ z, int steps, Dim3i d)
+{
+    __shared__ float sz[kSmoothLdsCells];
+    __shared__ float sr[kSmoothLdsCells];
+    const int n = d.x * d.y * d.z, hx = (d.x + 1) >> 1, sy = d.x, sp = d.x * d.y;
+    for (int c = threadIdx.x; c < n; c += kSmoothLdsThreads) {
+        sz[c] = z[c];
+        sr[c] = r[c];
+    }
+    __syncthreads();
+    for (int ph = 0; ph < 2 * steps; ++ph) {
+        for (int c = threadIdx.x; c < hx * d.y * d.z; c += kSmoothLdsThreads) {
+            const int t = c % hx, rest = c / hx, j = rest % d.y, k = rest / d.y;
+            const int i = 2 * t + ((j + k + ph) & 1);
+            if (i >= d.x) continue;
+            const int ind = i + j * sy + k * sp;
+            const float xm = i > 0 ? sz[ind - 1] : 0.f, xp = i + 1 < d.x ? sz[ind + 1] : 0.f;
+            const float ym = j > 0 ? sz[ind - sy] : 0.f, yp = j + 1 < d.y ? sz[ind + sy] : 0.f;
+            const float km = k > 0 ? sz[ind - sp] : 0.f, kp = k + 1 < d.z ? sz[ind + sp] : 0.f;
+            sz[ind] = fsk::div6(sr[ind] + (xm + xp + ym + yp + km + kp));
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < n; c += kSmoothLdsThreads) z[c] = sz[c];
+}
+
 // The eight SubRestrict launches of the reference, in their order, for one coarse cell: each
 // adds half the residual of one child (double product and sum, narrowed on the store).
 __global__ void k_restrict(const float* __restrict__ r, const float* __restrict__ z, float* __restrict__ rc, Dim3i d)
@@ -391,6 +424,12 @@ static long mg_tb_min_plane()
     return 128L * 128L;
 }
 
+static bool mg_no_lds_smoother()
+{
+    const char* e = getenv("FS_MG_NO_LDS");   // tests: force the per-colour launches on small levels
+    return e && atoi(e) != 0;
+}
+
 // One V-cycle (Solver.cu:1312-1366): M^-1 r, level 0 of r is the input.  The smoother ping-pongs
 // between z and zalt where it runs blocked, so the result is in either: the return value says
 // which.  zalt needs no clearing (a blocked pass writes every cell of its output).
@@ -416,6 +455,10 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
                 float* t = cur[l]; cur[l] = alt[l]; alt[l] = t;
                 phases -= take;
             }
+        }
+        if (phases > 0 && (size_t)d.x * d.y * d.z <= (size_t)kSmoothLdsCells && !mg_no_lds_smoother()) {
+            hipLaunchKernelGGL(k_smooth_lds, dim3(1), dim3(kSmoothLdsThreads), 0, st, r + offset, cur[l], phases / 2, d);
+            phases = 0;
         }
         for (int i = 0; i < phases; ++i)   // red, black, red, ... (phases is even here)
             hipLaunchKernelGGL(k_smooth, dim3(cdiv(cdiv(d.x, 2), 32), cdiv(d.y, 4), d.z), dim3(32, 4), 0, st,

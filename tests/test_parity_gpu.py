@@ -417,6 +417,9 @@ def test_mgpcg_steps_match_oracle(fs, oracle, dims, smoother, monkeypatch):
     temporally blocked kernel (by plane size; FS_MG_TB_MIN forces either)."""
     if smoother != "default":
         monkeypatch.setenv("FS_MG_TB_MIN", "0" if smoother == "blocked" else "1000000000")
+        # "plain" also takes the small levels through one launch per colour instead of the
+        # single-workgroup LDS smoother
+        monkeypatch.setenv("FS_MG_NO_LDS", "1" if smoother == "plain" else "0")
     elif dims[0] != 256:
         pytest.skip("the default threshold differs from 'plain' only on the large grid")
     steps = 2 if dims[0] == 256 else 3 if dims[0] == 64 else 5
