@@ -462,17 +462,20 @@ __device__ __forceinline__ float advect_component(const S& s, const GlobalSample
                          G.plane);
 }
 
-__host__ inline ZRange make_zrange(const FsGrid& g, int dz)
+// owned_only: the launch runs while the ghost planes are still being received, so a gather whose
+// taps leave the planes this rank owns (cells [z0, z0+nzl), faces [z0, z0+nzl]) must raise the flag
+__host__ inline ZRange make_zrange(const FsGrid& g, int dz, bool owned_only)
 {
     ZRange r;
     r.lo = g.wall_lo ? -2 : g.z0 - g.ghost;
     r.hi = g.wall_hi ? dz : g.z0 + g.nzl + g.ghost - 1;
-    r.chk_lo = g.wall_lo ? INT_MIN : r.lo;
-    r.chk_hi = g.wall_hi ? INT_MAX : r.hi;
+    r.chk_lo = g.wall_lo ? INT_MIN : (owned_only ? g.z0 : r.lo);
+    r.chk_hi = g.wall_hi ? INT_MAX : (owned_only ? g.z0 + g.nzl - 2 + (dz - g.nz) : r.hi);
     return r;
 }
 
-__host__ inline Vel make_vel(const FsGrid& g, const float* ux, const float* uy, const float* uz)
+__host__ inline Vel make_vel(const FsGrid& g, const float* ux, const float* uy, const float* uz,
+                             bool owned_only = false)
 {
     Vel v;
     ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
@@ -484,8 +487,8 @@ __host__ inline Vel make_vel(const FsGrid& g, const float* ux, const float* uy, 
     v.nz = g.nz;
     v.pitch = g.pitch;
     v.plane = g.plane;
-    v.zc = make_zrange(g, g.nz);
-    v.zf = make_zrange(g, g.nz + 1);
+    v.zc = make_zrange(g, g.nz, owned_only);
+    v.zf = make_zrange(g, g.nz + 1, owned_only);
     return v;
 }
 
@@ -728,21 +731,27 @@ int advect_velocity_launches(const FsGrid& g) { (void)g; return use_global_path(
 
 void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, float* nuz,
                      const float* ux, const float* uy, const float* uz, float dt, int scheme,
-                     int* halo_flag)
+                     int* halo_flag, int zb, int ze, bool owned_only)
 {
-    Vel v = make_vel(g, ux, uy, uz);
+    const int zend = g.z0 + g.nzl;
+    if (ze < 0) {   // default: everything this rank computes
+        zb = g.z0;
+        ze = zend + 1;
+    }
+    if (ze <= zb) return;
+    Vel v = make_vel(g, ux, uy, uz, owned_only);
     const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0;
     const ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
     float *ox = nux - zoff, *oy = nuy - zoff, *oz = nuz - zoff;
-    const int zend = g.z0 + g.nzl;
+    const int nzc = min(ze, zend) - zb;   // planes of [zb, ze) that hold ux / uy faces
     if (use_global_path()) {
-        launch_component_global<1>(st, ox, v, dt, mac, halo, 0, 0, g.z0, g.nx + 1, g.ny, g.nzl, false, halo_flag);
-        launch_component_global<2>(st, oy, v, dt, mac, halo, 0, 0, g.z0, g.nx, g.ny + 1, g.nzl, false, halo_flag);
-        launch_component_global<3>(st, oz, v, dt, mac, halo, 0, 0, g.z0, g.nx, g.ny, g.nzl + 1, false, halo_flag);
+        launch_component_global<1>(st, ox, v, dt, mac, halo, 0, 0, zb, g.nx + 1, g.ny, nzc, false, halo_flag);
+        launch_component_global<2>(st, oy, v, dt, mac, halo, 0, 0, zb, g.nx, g.ny + 1, nzc, false, halo_flag);
+        launch_component_global<3>(st, oz, v, dt, mac, halo, 0, 0, zb, g.nx, g.ny, ze - zb, false, halo_flag);
         return;
     }
     // brick kernel: all faces with i < nx; the ux faces at i = nx go through the global path
-    Box B = make_box(kBX, kBY, kBZ, 0, 0, g.z0, g.nx, g.ny + 1, g.nzl + 1);
+    Box B = make_box(kBX, kBY, kBZ, 0, 0, zb, g.nx, g.ny + 1, ze - zb);
 #define FS_CALL(M, H)                                                                              \
     do {                                                                                           \
         if (narrow_brick())                                                                        \
@@ -754,18 +763,23 @@ void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, fl
     } while (0)
     FS_DISPATCH_MH(mac, halo, FS_CALL);
 #undef FS_CALL
-    launch_component_global<1>(st, ox, v, dt, mac, halo, g.nx, 0, g.z0, 1, g.ny, g.nzl, true, halo_flag);
+    launch_component_global<1>(st, ox, v, dt, mac, halo, g.nx, 0, zb, 1, g.ny, nzc, true, halo_flag);
 }
 
 bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
                     float* nrho, const float* ux, const float* uy, const float* uz, float dt,
-                    int scheme, int* halo_flag, float* div)
+                    int scheme, int* halo_flag, float* div, int zb, int ze, bool owned_only)
 {
-    Vel v = make_vel(g, ux, uy, uz);
+    if (ze < 0) {   // default: all owned cell planes
+        zb = g.z0;
+        ze = g.z0 + g.nzl;
+    }
+    if (ze <= zb) return div != nullptr && scalars_use_lds();
+    Vel v = make_vel(g, ux, uy, uz, owned_only);
     const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0;
     const ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
     if (!scalars_use_lds()) {
-        Box B = make_box(64, 4, 1, 0, 0, g.z0, g.nx, g.ny, g.nzl);
+        Box B = make_box(64, 4, 1, 0, 0, zb, g.nx, g.ny, ze - zb);
 #define FS_CALL(M, H)                                                                             \
     hipLaunchKernelGGL((k_advect_scalars_global<M, H, 64, 4, 1>), dim3(B.nb), dim3(256), 0, st,   \
                        T - zoff, nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag)
@@ -773,7 +787,7 @@ bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, 
 #undef FS_CALL
         return false;
     }
-    Box B = make_box(kBX, kBY, kBZ, 0, 0, g.z0, g.nx, g.ny, g.nzl);
+    Box B = make_box(kBX, kBY, kBZ, 0, 0, zb, g.nx, g.ny, ze - zb);
     float* dv = div ? div - zoff : nullptr;
 #define FS_CALL2(D, M, H, DV)                                                                     \
     hipLaunchKernelGGL((k_advect_scalars_lds<D, M, H, DV>), dim3(B.nb), dim3(kThreads), 0, st, T - zoff, \

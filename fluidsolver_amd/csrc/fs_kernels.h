@@ -54,16 +54,20 @@ void fill_interior(hipStream_t st, const FsGrid& g, float* f, float value);
 void source(hipStream_t st, const FsGrid& g, const FsSource& src, float* rho, float* T);
 void force_uy(hipStream_t st, const FsGrid& g, float* uy, const float* T, float dt, float T_env);
 // Advect all three velocity components from the old velocity (ux,uy,uz) into (nux,nuy,nuz).
+// [zb, ze): the planes to produce (global indices within [z0, z0 + nzl], the last being the shared
+// uz face plane); ze < 0 = all of them.  owned_only: the ghost planes are not valid yet, so a
+// back-trace that needs one raises the halo flag instead of reading it.
 void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, float* nuz,
                      const float* ux, const float* uy, const float* uz, float dt, int scheme,
-                     int* halo_flag);
+                     int* halo_flag, int zb = 0, int ze = -1, bool owned_only = false);
 int advect_velocity_launches(const FsGrid& g);
 // T and rho share one back-trace (same sample position, Solver.cu:381-383 with dir = 0).
-// With div != nullptr the divergence of (ux,uy,uz) over the owned cells is written as well (single
-// slab only); returns whether it was.
+// With div != nullptr the divergence of (ux,uy,uz) over the produced cells is written as well;
+// returns whether it was.  [zb, ze) within [z0, z0 + nzl) and owned_only as above.
 bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
                     float* nrho, const float* ux, const float* uy, const float* uz, float dt,
-                    int scheme, int* halo_flag, float* div = nullptr);
+                    int scheme, int* halo_flag, float* div = nullptr, int zb = 0, int ze = -1,
+                    bool owned_only = false);
 // cell planes [zb, ze) (global indices); the faces uz[ze] must be held locally
 void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, const float* uy,
                 const float* uz, int zb, int ze);

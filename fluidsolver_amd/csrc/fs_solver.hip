@@ -376,6 +376,24 @@ int ensure_advect_ghosts(fs_solver* s)
     return rc;
 }
 
+// start the exchange ensure_advect_ghosts would make, without waiting for it; the caller sets the
+// validity flags after exchange_wait()
+int advect_ghosts_begin(fs_solver* s)
+{
+    Seg segs[5];
+    int n = 0;
+    if (!s->vel_ghost_ok) {
+        segs[n++] = make_seg(s, s->f.ux, s->g.ghost, false);
+        segs[n++] = make_seg(s, s->f.uy, s->g.ghost, false);
+        segs[n++] = make_seg(s, s->f.uz, s->g.ghost, true);
+    }
+    if (!s->scal_ghost_ok) {
+        segs[n++] = make_seg(s, s->f.T, s->g.ghost, false);
+        segs[n++] = make_seg(s, s->f.rho, s->g.ghost, false);
+    }
+    return exchange_begin(s, segs, n);
+}
+
 int ensure_p_ghosts(fs_solver* s, int planes)
 {
     if (s->world == 1) return FS_OK;
@@ -926,26 +944,58 @@ static int stage_advect(fs_solver* s, bool fuse_div)
     FsFields& f = s->f;
     const float dt = s->prm.dt;
     const int sc = s->prm.scheme;
-    int rc = ensure_advect_ghosts(s);
-    if (rc) return rc;
+    const FsGrid& g = s->g;
+    int rc;
+    // A slab hides each ghost exchange behind the planes that cannot need it: a back-trace stays
+    // within `ghost` planes (or raises the halo flag), so the planes at least that far from a
+    // neighbour are produced while the ghost planes travel, the others after they have arrived.
+    const int m_lo = g.wall_lo ? 0 : g.ghost, m_hi = g.wall_hi ? 0 : g.ghost;
+    const bool split = s->world > 1 && g.nzl >= m_lo + m_hi + 4;
+    const int z0 = g.z0, z1 = g.z0 + g.nzl;
     // Solver.cu:1153-1158: all three components from the OLD velocity, then swap
-    {
-        StageScope ps(s, FS_STAGE_ADVECT_VELOCITY, fsk::advect_velocity_launches(s->g));
-        fsk::advect_velocity(s->st, s->g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    if (!split) {
+        if ((rc = ensure_advect_ghosts(s))) return rc;
+        StageScope ps(s, FS_STAGE_ADVECT_VELOCITY, fsk::advect_velocity_launches(g));
+        fsk::advect_velocity(s->st, g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag);
+    } else {
+        StageScope ps(s, FS_STAGE_ADVECT_VELOCITY, 3 * fsk::advect_velocity_launches(g));
+        if ((rc = advect_ghosts_begin(s))) return rc;
+        fsk::advect_velocity(s->st, g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag, z0 + m_lo,
+                             z1 - m_hi + (g.wall_hi ? 1 : 0), true);
+        if ((rc = exchange_wait(s))) return rc;
+        s->vel_ghost_ok = s->scal_ghost_ok = true;
+        fsk::advect_velocity(s->st, g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag, z0, z0 + m_lo);
+        if (!g.wall_hi)
+            fsk::advect_velocity(s->st, g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag, z1 - m_hi,
+                                 z1 + 1);
     }
     std::swap(f.ux, f.nux);
     std::swap(f.uy, f.nuy);
     std::swap(f.uz, f.nuz);
     s->vel_ghost_ok = false;
-    if ((rc = ensure_velocity_ghosts(s))) return rc;
-    // Solver.cu:1160-1164: T then rho with the NEW (advected, unprojected) velocity
-    {
+    // Solver.cu:1160-1164: T then rho with the NEW (advected, unprojected) velocity.  The kernel
+    // also leaves the divergence of the new velocity behind for the owned cells, unless the
+    // confinement force is still to change that velocity.
+    float* div = (fuse_div && !(s->prm.flags & FS_FLAG_VORT_CONFINE)) ? f.div : nullptr;
+    if (!split) {
+        if ((rc = ensure_velocity_ghosts(s))) return rc;
         StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 1);
-        // the kernel also leaves the divergence of the new velocity behind for the owned cells,
-        // unless the confinement force is still to change that velocity
-        float* div = (fuse_div && !(s->prm.flags & FS_FLAG_VORT_CONFINE)) ? f.div : nullptr;
-        s->div_fresh = fsk::advect_scalars(s->st, s->g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc,
+        s->div_fresh = fsk::advect_scalars(s->st, g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc,
                                            s->d_flag, div);
+    } else {
+        StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 3);
+        Seg segs[3] = {make_seg(s, f.ux, g.ghost, false), make_seg(s, f.uy, g.ghost, false),
+                       make_seg(s, f.uz, g.ghost, true)};
+        if ((rc = exchange_begin(s, segs, 3))) return rc;
+        bool fresh = fsk::advect_scalars(s->st, g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag,
+                                         div, z0 + m_lo, z1 - m_hi, true);
+        if ((rc = exchange_wait(s))) return rc;
+        s->vel_ghost_ok = true;
+        fresh &= fsk::advect_scalars(s->st, g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag, div,
+                                     z0, z0 + m_lo);
+        fresh &= fsk::advect_scalars(s->st, g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag, div,
+                                     z1 - m_hi, z1);
+        s->div_fresh = fresh;
     }
     std::swap(f.T, f.nT);
     std::swap(f.rho, f.nrho);

@@ -31,6 +31,8 @@ def run_ranks(world, args, port, env_extra=None):
     (2, (18, 16, 24), 4, 6, ["naive"]),      # nx % 4 != 0 -> single sweeps, one plane per sweep
     (2, (32, 16, 26), 3, 8, ["random"]),     # random initial state uploaded per rank
     (4, (16, 16, 40), 4, 12, []),            # interior ranks have two neighbours
+    (3, (20, 16, 48), 3, 8, ["random"]),     # 16 planes per rank: the interior rank also advects its
+                                             # inner planes while the ghost planes travel
 ])
 def test_slab_matches_oracle(world, dims, steps, k, extra):
     run_ranks(world, ["host", *dims, steps, k, *extra], 29611 + world)
