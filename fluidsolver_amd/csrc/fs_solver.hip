@@ -23,9 +23,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <functional>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -156,6 +159,7 @@ struct fs_solver {
     void* xctx = nullptr;
     hipStream_t cs = nullptr;         // communication stream
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool host_two_streams = false;    // host-staged transport ordered through both streams (tests)
     char* h_stage[4] = {};            // pinned: send_lo, recv_lo, send_hi, recv_hi
     size_t h_stage_cap = 0;
     bool vel_ghost_ok = false, scal_ghost_ok = false;
@@ -268,65 +272,83 @@ int exchange_wait(fs_solver* s)
     return FS_OK;
 }
 
-int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
+// `produce`, if given, enqueues on the stream it is handed the kernels whose output the exchange
+// sends.  RCCL transport: they run on the communication stream (highest priority), ordered after
+// everything enqueued on the compute stream so far, and so overlap with what the caller enqueues
+// on the compute stream next; the transfer follows them there.  Host-staged transport: by default
+// everything stays on the compute stream and the call returns with the planes received (ranks
+// that share one GPU and each wait across two queues were seen to stall one another); with
+// FS_XCHG_STREAMS=1 it follows the two-stream ordering of the RCCL transport (tests).
+int exchange_begin(fs_solver* s, const Seg* segs, int nseg, const std::function<void(hipStream_t)>& produce = nullptr)
 {
-    if (s->world == 1 || nseg == 0) return FS_OK;
+    if (s->world == 1 || nseg == 0) {
+        if (produce) produce(s->st);
+        return FS_OK;
+    }
     {
         int rc = exchange_wait(s);   // one exchange in flight at a time
         if (rc) return rc;
     }
     const bool lo = !s->g.wall_lo, hi = !s->g.wall_hi;
+    const bool two_streams = s->comm != nullptr || s->host_two_streams;
+    hipStream_t q = s->st;
+    if (two_streams) {
+        // the communication stream waits for the producers on the compute stream ...
+        q = s->cs;
+        FS_HIP(hipEventRecord(s->ev_ready, s->st));
+        FS_HIP(hipStreamWaitEvent(q, s->ev_ready, 0));
+    }
+    if (produce) produce(q);
     if (s->comm) {
         Rccl* R = rccl();
-        // communication stream waits for the producers on the compute stream ...
-        FS_HIP(hipEventRecord(s->ev_ready, s->st));
-        FS_HIP(hipStreamWaitEvent(s->cs, s->ev_ready, 0));
         FS_NCCL(R->GroupStart());
-        for (int q = 0; q < nseg; ++q) {
-            const Seg& g = segs[q];
+        for (int i = 0; i < nseg; ++i) {
+            const Seg& g = segs[i];
             if (lo) {
-                FS_NCCL(R->Send(g.send_lo, g.n, ncclFloat, s->rank - 1, s->comm, s->cs));
-                FS_NCCL(R->Recv(g.recv_lo, g.n, ncclFloat, s->rank - 1, s->comm, s->cs));
+                FS_NCCL(R->Send(g.send_lo, g.n, ncclFloat, s->rank - 1, s->comm, q));
+                FS_NCCL(R->Recv(g.recv_lo, g.n, ncclFloat, s->rank - 1, s->comm, q));
             }
             if (hi) {
-                FS_NCCL(R->Send(g.send_hi, g.n, ncclFloat, s->rank + 1, s->comm, s->cs));
-                FS_NCCL(R->Recv(g.recv_hi, g.n, ncclFloat, s->rank + 1, s->comm, s->cs));
+                FS_NCCL(R->Send(g.send_hi, g.n, ncclFloat, s->rank + 1, s->comm, q));
+                FS_NCCL(R->Recv(g.recv_hi, g.n, ncclFloat, s->rank + 1, s->comm, q));
             }
         }
         FS_NCCL(R->GroupEnd());
-        // ... and the consumers on the compute stream wait for the halos in exchange_wait()
-        FS_HIP(hipEventRecord(s->ev_done, s->cs));
-        s->halo_pending = true;
-        return FS_OK;
-    }
-    // host-staged transport: pack through pinned buffers, let the caller's function move them
-    size_t bytes = 0;
-    for (int q = 0; q < nseg; ++q) bytes += segs[q].n * sizeof(float);
-    if (bytes > s->h_stage_cap) {
-        for (char*& b : s->h_stage) {
-            if (b) (void)hipHostFree(b);
-            b = nullptr;
-            FS_HIP(hipHostMalloc((void**)&b, bytes));
+    } else {
+        // host-staged transport: pack through pinned buffers, let the caller's function move them
+        size_t bytes = 0;
+        for (int i = 0; i < nseg; ++i) bytes += segs[i].n * sizeof(float);
+        if (bytes > s->h_stage_cap) {
+            for (char*& b : s->h_stage) {
+                if (b) (void)hipHostFree(b);
+                b = nullptr;
+                FS_HIP(hipHostMalloc((void**)&b, bytes));
+            }
+            s->h_stage_cap = bytes;
         }
-        s->h_stage_cap = bytes;
+        size_t off = 0;
+        for (int i = 0; i < nseg; ++i) {
+            const size_t nb = segs[i].n * sizeof(float);
+            if (lo) FS_HIP(hipMemcpyAsync(s->h_stage[0] + off, segs[i].send_lo, nb, hipMemcpyDeviceToHost, q));
+            if (hi) FS_HIP(hipMemcpyAsync(s->h_stage[2] + off, segs[i].send_hi, nb, hipMemcpyDeviceToHost, q));
+            off += nb;
+        }
+        FS_HIP(hipStreamSynchronize(q));
+        int rc = s->xfn(s->xctx, FS_XCHG_HALO, lo ? s->h_stage[0] : nullptr, lo ? s->h_stage[1] : nullptr,
+                        hi ? s->h_stage[2] : nullptr, hi ? s->h_stage[3] : nullptr, bytes);
+        if (rc) return fail(FS_ERR_COMM, "rank %d: the exchange callback returned %d", s->rank, rc);
+        off = 0;
+        for (int i = 0; i < nseg; ++i) {
+            const size_t nb = segs[i].n * sizeof(float);
+            if (lo) FS_HIP(hipMemcpyAsync(segs[i].recv_lo, s->h_stage[1] + off, nb, hipMemcpyHostToDevice, q));
+            if (hi) FS_HIP(hipMemcpyAsync(segs[i].recv_hi, s->h_stage[3] + off, nb, hipMemcpyHostToDevice, q));
+            off += nb;
+        }
     }
-    size_t off = 0;
-    for (int q = 0; q < nseg; ++q) {
-        const size_t nb = segs[q].n * sizeof(float);
-        if (lo) FS_HIP(hipMemcpyAsync(s->h_stage[0] + off, segs[q].send_lo, nb, hipMemcpyDeviceToHost, s->st));
-        if (hi) FS_HIP(hipMemcpyAsync(s->h_stage[2] + off, segs[q].send_hi, nb, hipMemcpyDeviceToHost, s->st));
-        off += nb;
-    }
-    FS_HIP(hipStreamSynchronize(s->st));
-    int rc = s->xfn(s->xctx, FS_XCHG_HALO, lo ? s->h_stage[0] : nullptr, lo ? s->h_stage[1] : nullptr,
-                    hi ? s->h_stage[2] : nullptr, hi ? s->h_stage[3] : nullptr, bytes);
-    if (rc) return fail(FS_ERR_COMM, "rank %d: the exchange callback returned %d", s->rank, rc);
-    off = 0;
-    for (int q = 0; q < nseg; ++q) {
-        const size_t nb = segs[q].n * sizeof(float);
-        if (lo) FS_HIP(hipMemcpyAsync(segs[q].recv_lo, s->h_stage[1] + off, nb, hipMemcpyHostToDevice, s->st));
-        if (hi) FS_HIP(hipMemcpyAsync(segs[q].recv_hi, s->h_stage[3] + off, nb, hipMemcpyHostToDevice, s->st));
-        off += nb;
+    if (two_streams) {
+        // ... and the consumers on the compute stream wait for the halos in exchange_wait()
+        FS_HIP(hipEventRecord(s->ev_done, q));
+        s->halo_pending = true;
     }
     return FS_OK;
 }
@@ -440,9 +462,11 @@ int run_jacobi(fs_solver* s, int sweeps)
             if (split) {
                 // boundary layers [z0, z0+T) and [z1-T, z1) (none at a global wall), then interior
                 const int ilo = g.wall_lo ? g.z0 : g.z0 + T, ihi = g.wall_hi ? z1 : z1 - T;
-                fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, g.z0, ilo, ihi, z1);
+                // (on the communication stream, so the interior of this pass does not wait for them)
                 Seg seg = make_seg(s, s->f.np, T, false);
-                rc = exchange_begin(s, &seg, 1);
+                rc = exchange_begin(s, &seg, 1, [&](hipStream_t q) {
+                    fsk::jacobi_pass(q, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, g.z0, ilo, ihi, z1);
+                });
                 if (rc) return rc;
                 fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, ilo, ihi);
                 std::swap(s->f.p, s->f.np);
@@ -731,9 +755,12 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         if (world > 1) {
             // the halo transfers are short and sit on the critical path of the next pass: give
             // their stream the highest priority so they are not queued behind the interior kernels
+            // (RCCL transport only: host-staged ranks may share one GPU, where several processes'
+            // high-priority queues waiting on their own normal-priority queues starve each other)
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-            if (hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            if (const char* e = getenv("FS_XCHG_STREAMS")) s->host_two_streams = atoi(e) != 0;
+            if (hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, unique_id ? prio_hi : prio_lo) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming) != hipSuccess) {
                 rc = fail(FS_ERR_HIP, "fs_create_slab: stream/event creation failed");

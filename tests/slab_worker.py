@@ -17,6 +17,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
+    # a stuck worker prints the Python stacks of its threads and exits instead of waiting for the
+    # parent's time limit
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("FS_WORKER_DUMP_AFTER", "200")), exit=True)
     import torch
     import torch.distributed as dist
     import fluidsolver_amd as fs

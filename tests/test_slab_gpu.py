@@ -52,3 +52,4 @@ def test_slab_convergence_mode():
 def test_single_rank_rccl_communicator():
     """world = 1 through the RCCL code path: loads librccl, creates the unique id."""
     run_ranks(1, ["rccl", 16, 16, 16, 2, 8], 29641)
+
