@@ -159,7 +159,7 @@ struct fs_solver {
     void* xctx = nullptr;
     hipStream_t cs = nullptr;         // communication stream
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    bool host_two_streams = false;    // host-staged transport ordered through both streams (tests)
+    int xchg_streams = -1;            // FS_XCHG_STREAMS: 1 / 0 force the two-stream / one-stream ordering
     char* h_stage[4] = {};            // pinned: send_lo, recv_lo, send_hi, recv_hi
     size_t h_stage_cap = 0;
     bool vel_ghost_ok = false, scal_ghost_ok = false;
@@ -277,8 +277,8 @@ int exchange_wait(fs_solver* s)
 // everything enqueued on the compute stream so far, and so overlap with what the caller enqueues
 // on the compute stream next; the transfer follows them there.  Host-staged transport: by default
 // everything stays on the compute stream and the call returns with the planes received (ranks
-// that share one GPU and each wait across two queues were seen to stall one another); with
-// FS_XCHG_STREAMS=1 it follows the two-stream ordering of the RCCL transport (tests).
+// that share one GPU and each wait across two queues were seen to stall one another).
+// FS_XCHG_STREAMS=1 / 0 forces the two-stream / one-stream ordering on either transport.
 int exchange_begin(fs_solver* s, const Seg* segs, int nseg, const std::function<void(hipStream_t)>& produce = nullptr)
 {
     if (s->world == 1 || nseg == 0) {
@@ -290,7 +290,7 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg, const std::function<
         if (rc) return rc;
     }
     const bool lo = !s->g.wall_lo, hi = !s->g.wall_hi;
-    const bool two_streams = s->comm != nullptr || s->host_two_streams;
+    const bool two_streams = s->xchg_streams >= 0 ? s->xchg_streams != 0 : s->comm != nullptr;
     hipStream_t q = s->st;
     if (two_streams) {
         // the communication stream waits for the producers on the compute stream ...
@@ -759,7 +759,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             // high-priority queues waiting on their own normal-priority queues starve each other)
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-            if (const char* e = getenv("FS_XCHG_STREAMS")) s->host_two_streams = atoi(e) != 0;
+            if (const char* e = getenv("FS_XCHG_STREAMS")) s->xchg_streams = atoi(e) != 0;
             if (hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, unique_id ? prio_hi : prio_lo) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming) != hipSuccess) {
