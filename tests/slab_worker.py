@@ -51,6 +51,27 @@ def main():
         for fid, arr in st.items():
             s.upload_global(fid, arr)
             o.set(fid, arr)
+    if "toofast" in extra:
+        # a uniform uz whose back-trace crosses more planes per step than the slabs' ghost depth:
+        # every rank with a neighbour below must report FS_ERR_HALO at the next sync, none may
+        # return fields computed from planes it does not hold
+        for fid, shape_z in ((fs.FS_UX, nz), (fs.FS_UY, nz), (fs.FS_UZ, nz + 1)):
+            full = np.zeros((shape_z,) + fs.field_shape(fid, nx, ny, nz)[1:], np.float32)
+            if fid == fs.FS_UZ:
+                full[:] = 30.0
+            s.upload_global(fid, full)
+        code = 0
+        try:
+            s.step()
+            s.sync()
+        except fs.FsError as e:
+            code = e.code
+        codes = [None] * world
+        dist.all_gather_object(codes, code)
+        ok = all(c == (0 if r == 0 else -4) for r, c in enumerate(codes))
+        if not ok:
+            print("rank %d: error codes %r" % (rank, codes))
+        steps = 0
     for step in range(steps):
         s.step()
         if "converge" in extra:

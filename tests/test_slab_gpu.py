@@ -49,6 +49,12 @@ def test_slab_convergence_mode():
     run_ranks(2, ["host", 24, 24, 24, 3, 0, "converge"], 29631)
 
 
+def test_slab_reports_a_back_trace_beyond_the_ghost_planes():
+    """|uz| dt = 6 planes against 4 ghost planes: FS_ERR_HALO on every rank with a lower
+    neighbour (also from the inner planes, which are advected before the ghost planes arrive)."""
+    run_ranks(3, ["host", 16, 16, 48, 1, 4, "toofast"], 29651)
+
+
 def test_single_rank_rccl_communicator():
     """world = 1 through the RCCL code path: loads librccl, creates the unique id."""
     run_ranks(1, ["rccl", 16, 16, 16, 2, 8], 29641)
