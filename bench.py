@@ -117,6 +117,8 @@ def stage_rooflines(prof, cells, steps, iters, n):
     for name, (ms, launches) in prof.items():
         if ms <= 0 or name not in BYTES_PER_CELL:
             continue
+        if name == "divergence" and ms / steps < 0.05:
+            continue   # fused into the scalar advection: what is left are a slab's few outer planes
         bpc = BYTES_PER_CELL[name] * (iters if name == "jacobi" else 1)
         gbs = bpc * cells * steps / (ms * 1e-3) / 1e9
         e = {"ms_per_step": ms / steps, "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
