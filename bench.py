@@ -283,6 +283,8 @@ def main():
             "step_hbm_frac": step_bytes_per_cell(sweeps_done / args.steps) * cells_rank / (ms_per_step * 1e-3)
                              / 1e9 / HBM_PEAK_GBS,
             "stage_ms_per_step": stage_ms,
+            # secondary metric: lattice updates per second of the pressure sweeps alone (per GPU)
+            "jacobi_lups": (cells_rank * sweeps_done / (prof["jacobi"][0] * 1e-3)) if prof.get("jacobi", (0, 0))[0] > 0 else None,
             "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, sweeps_done / args.steps, n),
             "roofline": {
                 "kernel": dom,
