@@ -159,6 +159,7 @@ struct fs_solver {
     void* xctx = nullptr;
     hipStream_t cs = nullptr;         // communication stream
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool self_peer = false;           // FS_TEST_SELF_PEER: both neighbours are this rank itself (tests)
     int xchg_streams = -1;            // FS_XCHG_STREAMS: 1 / 0 force the two-stream / one-stream ordering
     char* h_stage[4] = {};            // pinned: send_lo, recv_lo, send_hi, recv_hi
     size_t h_stage_cap = 0;
@@ -301,16 +302,17 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg, const std::function<
     if (produce) produce(q);
     if (s->comm) {
         Rccl* R = rccl();
+        const int peer_lo = s->self_peer ? 0 : s->rank - 1, peer_hi = s->self_peer ? 0 : s->rank + 1;
         FS_NCCL(R->GroupStart());
         for (int i = 0; i < nseg; ++i) {
             const Seg& g = segs[i];
             if (lo) {
-                FS_NCCL(R->Send(g.send_lo, g.n, ncclFloat, s->rank - 1, s->comm, q));
-                FS_NCCL(R->Recv(g.recv_lo, g.n, ncclFloat, s->rank - 1, s->comm, q));
+                FS_NCCL(R->Send(g.send_lo, g.n, ncclFloat, peer_lo, s->comm, q));
+                FS_NCCL(R->Recv(g.recv_lo, g.n, ncclFloat, peer_lo, s->comm, q));
             }
             if (hi) {
-                FS_NCCL(R->Send(g.send_hi, g.n, ncclFloat, s->rank + 1, s->comm, q));
-                FS_NCCL(R->Recv(g.recv_hi, g.n, ncclFloat, s->rank + 1, s->comm, q));
+                FS_NCCL(R->Send(g.send_hi, g.n, ncclFloat, peer_hi, s->comm, q));
+                FS_NCCL(R->Recv(g.recv_hi, g.n, ncclFloat, peer_hi, s->comm, q));
             }
         }
         FS_NCCL(R->GroupEnd());
@@ -774,7 +776,11 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                 }
                 ncclUniqueId id;
                 std::memcpy(&id, unique_id, sizeof(id));
-                ncclResult_t ne = R->CommInitRank(&s->comm, world, id, rank);
+                // FS_TEST_SELF_PEER (tests on one GPU): a communicator of this rank alone; the slab
+                // keeps its place in the decomposition but trades planes with itself, which drives
+                // the RCCL calls and the stream ordering without a second device
+                s->self_peer = getenv("FS_TEST_SELF_PEER") != nullptr;
+                ncclResult_t ne = R->CommInitRank(&s->comm, s->self_peer ? 1 : world, id, s->self_peer ? 0 : rank);
                 if (ne != ncclSuccess) {
                     s->comm = nullptr;
                     rc = fail(FS_ERR_COMM, "fs_create_slab: ncclCommInitRank failed: %s", R->GetErrorString(ne));

@@ -16,6 +16,43 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def self_peer(fs, nx, ny, nz, steps, kw):
+    """The middle slab of three, alone on this GPU, trading its boundary planes with itself over
+    RCCL (FS_TEST_SELF_PEER): no oracle for that, but the run with the transfers on the
+    communication stream (two events per exchange, Jacobi boundary launch on that stream) must
+    equal the run with everything on the compute stream, bit for bit, and neither may hang."""
+    import ctypes as C
+    from fluidsolver_amd import slab as slabmod
+    os.environ["FS_TEST_SELF_PEER"] = "1"
+    L = fs.load_library()
+    slabmod._bind(L)
+    rng = np.random.default_rng(11)
+    init = None
+    runs = []
+    for streams in ("1", "0"):
+        os.environ["FS_XCHG_STREAMS"] = streams
+        p = fs.default_params(nx, ny, 3 * nz, source_z=1.5 * nz, **kw)
+        s = slabmod.SlabSolver(p, 1, 3, transport="rccl")
+        uid = (C.c_char * slabmod.FS_UNIQUE_ID_BYTES)()
+        s._check(L.fs_comm_unique_id(uid))
+        h = C.c_void_p()
+        s._check(L.fs_create_slab(C.byref(p), 1, 3, uid, slabmod._EXCHANGE_FN(0), None, C.byref(h)))
+        s._h = h
+        if init is None:
+            init = {f: (rng.standard_normal(s.local_shape(f)) * (0.8 if f < 3 else 0.3)).astype(np.float32)
+                    for f in range(5)}
+        for f, a in init.items():
+            s.upload(f, a)
+        s.step(steps)
+        s.sync()
+        runs.append([s.field(f) for f in range(6)])
+        s.close()
+    ok = all(np.array_equal(a, b) for a, b in zip(*runs)) and all(np.isfinite(a).all() for a in runs[0])
+    moved = not np.array_equal(runs[0][0], init[0])
+    print("SLAB_OK" if ok and moved else "SLAB_FAIL")
+    sys.exit(0 if ok and moved else 1)
+
+
 def main():
     # a stuck worker prints the Python stacks of its threads and exits instead of waiting for the
     # parent's time limit
@@ -37,6 +74,8 @@ def main():
     dev = local_rank % max(ndev, 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     kw = dict(jacobi_iters=k, source_y=min(10.0, ny / 3.0), source_radius=min(7.0, min(nx, ny, nz) / 4.0))
+    if mode == "selfpeer":
+        return self_peer(fs, nx, ny, nz, steps, kw)
     if "naive" in extra:
         kw["flags"] = fs.FS_FLAG_JACOBI_NAIVE
     if "converge" in extra:

@@ -55,6 +55,12 @@ def test_slab_reports_a_back_trace_beyond_the_ghost_planes():
     run_ranks(3, ["host", 16, 16, 48, 1, 4, "toofast"], 29651)
 
 
+def test_rccl_send_recv_and_stream_ordering_with_itself_as_neighbour():
+    """RCCL on one GPU: the middle slab of three exchanges with itself (see slab_worker.self_peer);
+    two-stream ordering against one-stream ordering, 12 steps of 7 exchanges each."""
+    run_ranks(1, ["selfpeer", 64, 48, 24, 12, 20], 29661)
+
+
 def test_single_rank_rccl_communicator():
     """world = 1 through the RCCL code path: loads librccl, creates the unique id."""
     run_ranks(1, ["rccl", 16, 16, 16, 2, 8], 29641)
