@@ -23,8 +23,6 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#include <functional>
-
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -273,19 +271,15 @@ int exchange_wait(fs_solver* s)
     return FS_OK;
 }
 
-// `produce`, if given, enqueues on the stream it is handed the kernels whose output the exchange
-// sends.  RCCL transport: they run on the communication stream (highest priority), ordered after
-// everything enqueued on the compute stream so far, and so overlap with what the caller enqueues
-// on the compute stream next; the transfer follows them there.  Host-staged transport: by default
-// everything stays on the compute stream and the call returns with the planes received (ranks
-// that share one GPU and each wait across two queues were seen to stall one another).
+// RCCL transport: the transfer runs on the communication stream (highest priority), ordered after
+// everything enqueued on the compute stream so far, and overlaps with what the caller enqueues on
+// the compute stream next.  Host-staged transport: by default everything stays on the compute
+// stream and the call returns with the planes received (ranks that share one GPU and each wait
+// across two queues were seen to stall one another).
 // FS_XCHG_STREAMS=1 / 0 forces the two-stream / one-stream ordering on either transport.
-int exchange_begin(fs_solver* s, const Seg* segs, int nseg, const std::function<void(hipStream_t)>& produce = nullptr)
+int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
 {
-    if (s->world == 1 || nseg == 0) {
-        if (produce) produce(s->st);
-        return FS_OK;
-    }
+    if (s->world == 1 || nseg == 0) return FS_OK;
     {
         int rc = exchange_wait(s);   // one exchange in flight at a time
         if (rc) return rc;
@@ -299,7 +293,6 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg, const std::function<
         FS_HIP(hipEventRecord(s->ev_ready, s->st));
         FS_HIP(hipStreamWaitEvent(q, s->ev_ready, 0));
     }
-    if (produce) produce(q);
     if (s->comm) {
         Rccl* R = rccl();
         const int peer_lo = s->self_peer ? 0 : s->rank - 1, peer_hi = s->self_peer ? 0 : s->rank + 1;
@@ -464,11 +457,11 @@ int run_jacobi(fs_solver* s, int sweeps)
             if (split) {
                 // boundary layers [z0, z0+T) and [z1-T, z1) (none at a global wall), then interior
                 const int ilo = g.wall_lo ? g.z0 : g.z0 + T, ihi = g.wall_hi ? z1 : z1 - T;
-                // (on the communication stream, so the interior of this pass does not wait for them)
+                // (first on the compute stream: run beside the interior launch, which fills every CU,
+                // they took 180 us instead of 25 and delayed the transfer that waits for them)
+                fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, g.z0, ilo, ihi, z1);
                 Seg seg = make_seg(s, s->f.np, T, false);
-                rc = exchange_begin(s, &seg, 1, [&](hipStream_t q) {
-                    fsk::jacobi_pass(q, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, g.z0, ilo, ihi, z1);
-                });
+                rc = exchange_begin(s, &seg, 1);
                 if (rc) return rc;
                 fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, ilo, ihi);
                 std::swap(s->f.p, s->f.np);
