@@ -11,6 +11,9 @@ Files:
   plume32.npz  -- 32^3, K=20: all 7 fields after steps 2 and 10
   plume20_confined.npz -- 20^3, K=12, vorticity confinement on (defined-behaviour variant of the
                           shipped VORT_CONFINE build): ux, uy, uz, rho after steps 3 and 8
+  plume24_shipped.npz -- 24x32x24, the shipped configuration (MGPCG pressure solve + vorticity
+                          confinement, 30 CG iterations at most): ux, uy, uz, rho, p and the CG
+                          iteration count after steps 2 and 6
   plume64_stats.npz -- 64^3, K=20, 100 steps: per-field sum (f64) / L2 / max / argmax every 10
                        steps, the rho centre line rho[nz/2, :, nx/2] and 4096 fixed probe points
                        (index list stored in the file) at steps 50 and 100
@@ -51,6 +54,19 @@ def confined(n, steps_keep):
     return out
 
 
+def shipped(dims, steps_keep):
+    kw = dict(jacobi_iters=30, source_y=8.0, source_radius=5.0)
+    o = oracle.Oracle(oracle.default_params(*dims, vort_confine=1, pressure_solver=oracle.PRESSURE_MGPCG, **kw))
+    out = {"dims": np.array(dims), **kw}
+    for s in range(1, max(steps_keep) + 1):
+        o.step()
+        if s in steps_keep:
+            for f in (0, 1, 2, 3, 5):
+                out["s%d_%s" % (s, NAMES[f])] = o.get(f)
+            out["s%d_cg_iters" % s] = o.cg_info()[0]
+    return out
+
+
 def stats64():
     n = 64
     o = oracle.Oracle(oracle.default_params(n, n, n, jacobi_iters=20))
@@ -81,6 +97,7 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "plume16.npz"), **small(16, (1, 2, 10), 5.0, 4.0))
     np.savez_compressed(os.path.join(HERE, "plume32.npz"), **small(32, (2, 10), 8.0, 5.0))
     np.savez_compressed(os.path.join(HERE, "plume20_confined.npz"), **confined(20, (3, 8)))
+    np.savez_compressed(os.path.join(HERE, "plume24_shipped.npz"), **shipped((24, 32, 24), (2, 6)))
     np.savez_compressed(os.path.join(HERE, "plume64_stats.npz"), **stats64())
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

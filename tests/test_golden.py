@@ -71,6 +71,37 @@ def test_gpu_matches_confined_fixture(fs):
         lambda s, f: s.field(f), lambda s, k: s.step(k))
 
 
+def check_shipped(make, get, step_fn, iters_fn, exact):
+    g = load("plume24_shipped.npz")
+    dims = [int(v) for v in g["dims"]]
+    s = make(dims, int(g["jacobi_iters"]), float(g["source_y"]), float(g["source_radius"]))
+    done = 0
+    for st in (2, 6):
+        step_fn(s, st - done)
+        done = st
+        assert iters_fn(s) == int(g["s%d_cg_iters" % st])
+        for f in (0, 1, 2, 3, 5):
+            a, b = get(s, f), g["s%d_%s" % (st, NAMES[f])]
+            if exact:
+                assert np.array_equal(a, b), "shipped step %d %s" % (st, NAMES[f])
+            else:   # the dot products are summed in another order: equal unless a sum sits on a rounding boundary
+                assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-30), "shipped step %d %s" % (st, NAMES[f])
+
+
+def test_oracle_reproduces_shipped_fixture(oracle):
+    check_shipped(lambda d, k, sy, sr: oracle.Oracle(oracle.default_params(
+        *d, jacobi_iters=k, source_y=sy, source_radius=sr, vort_confine=1, pressure_solver=oracle.PRESSURE_MGPCG)),
+        lambda s, f: s.get(f), lambda s, k: s.step(k), lambda s: s.cg_info()[0], True)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_shipped_fixture(fs):
+    check_shipped(lambda d, k, sy, sr: fs.Solver(fs.default_params(
+        *d, jacobi_iters=k, source_y=sy, source_radius=sr, flags=fs.FS_FLAG_VORT_CONFINE,
+        pressure_solver=fs.FS_PRESSURE_MGPCG)).Initialize(),
+        lambda s, f: s.field(f), lambda s, k: s.step(k), lambda s: s.cg_info()[0], False)
+
+
 @pytest.mark.gpu
 def test_gpu_matches_small_fixtures(fs):
     def make(n, k, sy, sr):
