@@ -136,7 +136,9 @@ struct TbRange {
 //            multigrid smoother (Smooth, Solver.cu:848-860): level t updates the cells with
 //            (x + y + z + t - 1) even to (rhs + neibor_sum) / 6 and carries the others over, so a
 //            pass of T levels is T/2 sweeps, red colour first.  `div` holds the right-hand side.
-enum { kJacobi = 0, kRbgs = 1 };
+//   kRbgsZero  kRbgs whose input is known to be all zero (the first smoothing of a V-cycle level):
+//              level 0 is not loaded
+enum { kJacobi = 0, kRbgs = 1, kRbgsZero = 2 };
 
 // Level t of march step n: produces plane n-t of level t from planes n-t-1, n-t, n-t+1 of
 // level t-1 (registers), the y-neighbours of plane n-t (LDS, written by the previous step) and div.
@@ -220,7 +222,8 @@ __device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<C
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const f4 landed = R.q[PH & 1][c];                  // plane n
-        R.q[PH & 1][c] = plane_load(plane_rsrc(A.p, kp, A), L.ld_off[c]);
+        if constexpr (KIND == kRbgsZero) R.q[PH & 1][c] = f4{0.f, 0.f, 0.f, 0.f};
+        else R.q[PH & 1][c] = plane_load(plane_rsrc(A.p, kp, A), L.ld_off[c]);
         R.dv[wrap(PH + 1, 6)][c] = plane_load(plane_rsrc(A.div, kd, A), L.ld_off[c]);
         R.w0[PH % 3][c] = landed;
         lcur[L.row[c] * kW4] = landed;
@@ -481,7 +484,8 @@ bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, con
 
 // Red/black Gauss-Seidel on a dense nx x ny x nz array (rows unpadded): `phases` half-sweeps (2 or 4,
 // red first) from zin into zout; false if this grid cannot take the blocked kernel.
-bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases)
+bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases,
+               bool zin_is_zero)
 {
     FsGrid g{};
     g.nx = nx; g.ny = ny; g.nz = nz;
@@ -490,8 +494,13 @@ bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const f
     g.wall_lo = g.wall_hi = 1;
     const bool aligned = (((uintptr_t)rhs | (uintptr_t)zin | (uintptr_t)zout) & 15u) == 0;
     if (!can_block(g) || !aligned || (phases != 2 && phases != 4)) return false;
-    if (phases == 4) launch_tb<4, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz);
-    else launch_tb<2, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz);
+    if (zin_is_zero) {
+        if (phases == 4) launch_tb<4, kRbgsZero>(st, g, zin, zout, rhs, 0, nz, 0, nz);
+        else launch_tb<2, kRbgsZero>(st, g, zin, zout, rhs, 0, nz, 0, nz);
+    } else {
+        if (phases == 4) launch_tb<4, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz);
+        else launch_tb<2, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz);
+    }
     return true;
 }
 

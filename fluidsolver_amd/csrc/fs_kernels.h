@@ -110,7 +110,9 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
                        int init_smooth_steps, int bottom_smooth_steps);   // returns z or zalt: the result
 // `phases` (2 or 4) red/black Gauss-Seidel half-sweeps of the zero-outside operator on a dense
 // nx x ny x nz array in one blocked pass, zin -> zout; false if the grid cannot take it
-bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases);
+// (zin_is_zero: zin holds zeros and is not read)
+bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases,
+               bool zin_is_zero = false);
 // Vorticity confinement (single slab only).  The three vorticity arrays are dense, vort_elems(g)
 // floats each, zero-filled once by the owner.
 size_t vort_elems(const FsGrid& g);

@@ -437,7 +437,6 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
                        int init_smooth_steps, int bottom_smooth_steps)
 {
     const size_t space = mg_space(g, levels), n0 = (size_t)g.nx * g.ny * g.nz;
-    (void)hipMemsetAsync(z, 0, space * sizeof(float), st);
     if (space > n0) (void)hipMemsetAsync(r + n0, 0, (space - n0) * sizeof(float), st);
     const long tb_min = mg_tb_min_plane();
     constexpr int kMaxLevels = 16;
@@ -446,16 +445,20 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
     Dim3i d{g.nx, g.ny, g.nz};
     size_t offset = 0;
     int l = 0;
-    auto smooth = [&](int steps) {
+    // z starts at zero on every level: a blocked first pass takes that as known instead of
+    // reading it, any other smoother gets the level cleared first
+    auto smooth = [&](int steps, bool from_zero) {
         int phases = 2 * steps;
         if ((long)d.x * d.y >= tb_min) {
             while (phases >= 2) {
                 const int take = phases >= 4 ? 4 : 2;
-                if (!rbgs_pass(st, d.x, d.y, d.z, r + offset, cur[l], alt[l], take)) break;
+                if (!rbgs_pass(st, d.x, d.y, d.z, r + offset, cur[l], alt[l], take, from_zero)) break;
                 float* t = cur[l]; cur[l] = alt[l]; alt[l] = t;
                 phases -= take;
+                from_zero = false;
             }
         }
+        if (from_zero) (void)hipMemsetAsync(cur[l], 0, (size_t)d.x * d.y * d.z * sizeof(float), st);
         if (phases > 0 && (size_t)d.x * d.y * d.z <= (size_t)kSmoothLdsCells && !mg_no_lds_smoother()) {
             hipLaunchKernelGGL(k_smooth_lds, dim3(1), dim3(kSmoothLdsThreads), 0, st, r + offset, cur[l], phases / 2, d);
             phases = 0;
@@ -466,7 +469,7 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
     };
     for (; l < levels - 1; ++l) {
         cur[l] = z + offset; alt[l] = zalt + offset;
-        smooth(init_smooth_steps << l);
+        smooth(init_smooth_steps << l, true);
         const size_t n = (size_t)d.x * d.y * d.z;
         const Dim3i c{d.x / 2, d.y / 2, d.z / 2};
         // (the level offsets are even, so 8-byte loads are aligned whenever nx is even)
@@ -478,13 +481,13 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
         d = Dim3i{d.x >> 1, d.y >> 1, d.z >> 1};
     }
     cur[l] = z + offset; alt[l] = zalt + offset;
-    smooth(bottom_smooth_steps);
+    smooth(bottom_smooth_steps, true);
     for (l = levels - 2; l >= 0; --l) {
         d = Dim3i{d.x << 1, d.y << 1, d.z << 1};
         const size_t n = (size_t)d.x * d.y * d.z;
         offset -= n;
         hipLaunchKernelGGL(k_prolongate, grid3(d), dim3(64, 4), 0, st, cur[l], cur[l + 1], d);
-        smooth(init_smooth_steps << l);
+        smooth(init_smooth_steps << l, false);
     }
     return cur[0];
 }
