@@ -349,16 +349,16 @@ constexpr TbConfig kConfigs[] = {{64, 1}, {32, 1}};
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 // Tile variant for a grid: 64-row tiles (one workgroup of 16 waves per CU) have the smaller halo
-// share and win on large planes; 32-row tiles (two workgroups per CU) give four times as many
-// workgroups per plane and win up to 256^2 (measured 256^3: 1.88 vs 2.15 ms per 80 sweeps,
-// 128^3: 0.26 vs 0.38 ms per 40).  FS_JACOBI_CFG overrides.
+// share and win on large planes; 32-row tiles (two workgroups per CU) give more workgroups per
+// plane and win on small ones.  Measured per 80 sweeps, 32-row vs 64-row tiles: 128^3 0.38 vs
+// 0.56 ms, 192^3 0.667 vs 0.670, 256^3 1.11 vs 1.05, 384^3 4.16 vs 3.63.  FS_JACOBI_CFG overrides.
 int tb_config(const FsGrid& g)
 {
     if (const char* e = getenv("FS_JACOBI_CFG")) {   // read per launch: tests switch it
         const int v = atoi(e);
         if (v >= 0 && v < kNumConfigs) return v;
     }
-    return (long)g.nx * g.ny >= 384L * 384L ? 0 : 1;
+    return (long)g.nx * g.ny >= 224L * 224L ? 0 : 1;
 }
 
 int tb_order()
