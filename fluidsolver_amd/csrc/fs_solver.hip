@@ -13,10 +13,9 @@
 // scalar advection.  A fused Jacobi pass first produces the jacobi_block() planes next to each
 // neighbour, sends them (one exchange per 4 sweeps) and produces the slab interior while they
 // travel; the gradient then finds the ghost planes of p already valid.  Planes are contiguous in
-// memory, so a halo is
-// one send and one receive per field and neighbour, straight from and into the arrays, with
-// RCCL (ncclSend/ncclRecv in one group, on a communication stream ordered against the compute
-// stream by events).  The only collective is the all-reduce of the residual norm.
+// memory, so a halo is one send and one receive per field and neighbour, straight from and into
+// the arrays, with RCCL (ncclSend/ncclRecv in one group, on a communication stream ordered against
+// the compute stream by events).  The only collective is the all-reduce of the residual norm.
 #include "../../include/fluidsolver.h"
 #include "fs_kernels.h"
 
@@ -73,23 +72,19 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-Rccl* rccl()
+bool load_rccl(Rccl& r)
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (r.lib) break;
     }
-    if (!r.lib) return nullptr;
+    if (!r.lib) return false;
 #define FS_SYM(field, name)                                                   \
     r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name));        \
     if (!r.field) {                                                           \
         r.lib = nullptr;                                                      \
-        return nullptr;                                                       \
+        return false;                                                         \
     }
     FS_SYM(GetUniqueId, "ncclGetUniqueId")
     FS_SYM(CommInitRank, "ncclCommInitRank")
@@ -101,7 +96,15 @@ Rccl* rccl()
     FS_SYM(AllReduce, "ncclAllReduce")
     FS_SYM(GetErrorString, "ncclGetErrorString")
 #undef FS_SYM
-    return &r;
+    return true;
+}
+
+// the library is looked up once, by whichever thread asks first
+Rccl* rccl()
+{
+    static Rccl r;
+    static const bool ok = load_rccl(r);
+    return ok ? &r : nullptr;
 }
 
 #define FS_NCCL(call)                                                                          \
