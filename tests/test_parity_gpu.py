@@ -165,6 +165,22 @@ def test_full_step_small(fs, oracle, n, steps, k):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("dims", [(4096, 4, 8), (8, 4096, 4), (4, 8, 4096), (4096, 1, 1)])
+def test_largest_extents(fs, oracle, dims):
+    """The largest extent the library accepts (4096) along each axis, on pencil-shaped grids: a
+    random state through every stage, then full steps with the source on."""
+    nx, ny, nz = dims
+    kw = dict(jacobi_iters=9, source_x=nx / 2.0, source_y=ny / 2.0, source_z=nz / 2.0, source_radius=3.0)
+    g, o = make_pair(fs, oracle, nx, ny, nz, **kw)
+    load_state(g, o, random_fields(nx, ny, nz, seed=sum(dims), vel_scale=2.0))
+    for stage in ("force", "advect", "project", "gradient"):
+        g.stage(stage); o.stage(stage)
+        assert_all_equal(g, o, fields=range(6), what="stage %s %s" % (stage, dims))
+    g.step(3); o.step(3)
+    assert_all_equal(g, o, what="steps %s" % (dims,))
+    g.close(); o.close()
+
+
 def test_default_shipped_grid(fs, oracle):
     """The reference's compiled-in grid 64x128x64 (Solver.h:9-11), 5 steps, K = 30."""
     g, o = make_pair(fs, oracle, 64, 128, 64)
