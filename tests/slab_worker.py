@@ -49,6 +49,22 @@ def self_peer(fs, nx, ny, nz, steps, kw):
         s.close()
     ok = all(np.array_equal(a, b) for a, b in zip(*runs)) and all(np.isfinite(a).all() for a in runs[0])
     moved = not np.array_equal(runs[0][0], init[0])
+    # convergence mode on the same slab: the residual norm goes through ncclAllReduce
+    del os.environ["FS_XCHG_STREAMS"]
+    p = fs.default_params(nx, ny, 3 * nz, source_z=1.5 * nz, tolerance=1e-2, check_every=8, max_sweeps=64,
+                          **{a: b for a, b in kw.items() if a != "jacobi_iters"})
+    s = slabmod.SlabSolver(p, 1, 3, transport="rccl")
+    uid = (C.c_char * slabmod.FS_UNIQUE_ID_BYTES)()
+    s._check(L.fs_comm_unique_id(uid))
+    h = C.c_void_p()
+    s._check(L.fs_create_slab(C.byref(p), 1, 3, uid, slabmod._EXCHANGE_FN(0), None, C.byref(h)))
+    s._h = h
+    for f, a in init.items():
+        s.upload(f, a)
+    s.step(2)
+    res = s.residual(0)
+    ok = ok and 8 <= s.last_sweeps <= 64 and np.isfinite(res) and (res < 1e-2 or s.last_sweeps == 64)
+    s.close()
     print("SLAB_OK" if ok and moved else "SLAB_FAIL")
     sys.exit(0 if ok and moved else 1)
 
