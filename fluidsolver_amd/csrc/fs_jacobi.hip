@@ -46,6 +46,9 @@ constexpr int kW4 = 16;          // float4 columns per tile row (one 16-lane DPP
 constexpr int kW = 4 * kW4;      // 64 cells per tile row
 constexpr int kHaloX = 4;        // x halo is one float4, enough for T <= 4 and keeps loads aligned
 constexpr int kBX = kW - 2 * kHaloX;
+// AX = 1 variant: two halo lanes per side, tile origin shifted by 8 cells, so a tile's output rows
+// are 48 cells = 192 bytes starting on a 64-byte boundary (no partly written 64-byte blocks)
+constexpr int tile_bx(int ax) { return ax ? kW - 16 : kBX; }
 
 struct TbArgs {
     const float* p;      // pre-offset: global z indexes directly
@@ -234,7 +237,7 @@ __device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<C
     __syncthreads();
 }
 
-template <int KIND, int T, int NTY, int CPT>
+template <int KIND, int T, int NTY, int CPT, int AX = 0>
 __global__ void __launch_bounds__(kW4 * NTY)
 k_jacobi_tb(TbArgs A)
 {
@@ -256,12 +259,13 @@ k_jacobi_tb(TbArgs A)
     // Tile (bx, by) covers cells [bx*kBX, bx*kBX + 64) x [by*BY, by*BY + H).  Its outer kHaloX
     // columns and T rows are halo, except where the tile edge is a wall: a wall cell needs nothing
     // from beyond the wall, so it is an output of the tile like an interior cell.
-    const int x = bx * kBX + 4 * L.tx;                           // first cell of the column
-    const bool x_in = x < A.nx;                                  // nx % 4 == 0: all four or none
+    const int x = bx * tile_bx(AX) + 4 * L.tx - (AX ? 8 : 0);    // first cell of the column
+    const bool x_in = x >= 0 && x < A.nx;                        // nx % 4 == 0: all four or none
     L.at_left = x == 0;
     L.at_right = x + 4 == A.nx;
-    const bool x_out = (L.tx >= 1 || L.at_left) && (L.tx < kW4 - 1 || L.at_right);
-    const int xc = min(x, A.nx - 4);
+    const bool x_out = AX ? (L.tx >= 2 && L.tx < kW4 - 2)
+                          : (L.tx >= 1 || L.at_left) && (L.tx < kW4 - 1 || L.at_right);
+    const int xc = max(0, min(x, A.nx - 4));
     const int y0 = by * BY;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
@@ -345,7 +349,7 @@ bool can_block(const FsGrid& g) { return g.nx % 4 == 0 && g.nx >= 8; }
 
 // tile variants: rows of threads (NTY) x columns per thread (CPT); tile rows H = NTY*CPT
 struct TbConfig { int nty, cpt; };
-constexpr TbConfig kConfigs[] = {{64, 1}, {32, 1}};
+constexpr TbConfig kConfigs[] = {{64, 1}, {32, 1}, {64, 1}, {32, 1}};   // 2, 3: 64-byte aligned output rows
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 // Tile variant for a grid: 64-row tiles (one workgroup of 16 waves per CU) have the smaller halo
@@ -358,6 +362,7 @@ int tb_config(const FsGrid& g)
         const int v = atoi(e);
         if (v >= 0 && v < kNumConfigs) return v;
     }
+    if (g.jacobi_tile > 0 && g.jacobi_tile <= kNumConfigs) return g.jacobi_tile - 1;
     return (long)g.nx * g.ny >= 224L * 224L ? 0 : 1;
 }
 
@@ -379,12 +384,12 @@ int tb_chunk_planes()
     return v;
 }
 
-template <int KIND, int T, int NTY, int CPT>
+template <int KIND, int T, int NTY, int CPT, int AX = 0>
 void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
 {
     constexpr int H = NTY * CPT, BY = H - 2 * T;
     // halo columns / rows at a wall are outputs, so the tiles need to cover n - 2*halo only
-    const int tiles_x = max(1, cdiv(g.nx - 2 * kHaloX, kBX));
+    const int tiles_x = AX ? cdiv(g.nx, tile_bx(1)) : max(1, cdiv(g.nx - 2 * kHaloX, kBX));
     const int tiles_y = max(1, cdiv(g.ny - 2 * T, BY));
     int tiles = tiles_x * tiles_y;
     const int n1 = A.zout_hi - A.zout_lo, n2 = max(0, A.zout2_hi - A.zout2_lo);
@@ -421,7 +426,7 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
     A.nblocks = A.tiles_x * A.tiles_y * chunks;
     A.order = tb_order();
     dim3 grid(A.nblocks), block(kW4, NTY);
-    hipLaunchKernelGGL((k_jacobi_tb<KIND, T, NTY, CPT>), grid, block, 0, st, A);
+    hipLaunchKernelGGL((k_jacobi_tb<KIND, T, NTY, CPT, AX>), grid, block, 0, st, A);
 }
 
 template <int T, int KIND = kJacobi>
@@ -442,6 +447,8 @@ void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const
     A.lz = 0;
     switch (tb_config(g)) {
     case 1: launch_tb_cfg<KIND, T, 32, 1>(st, g, A); break;
+    case 2: launch_tb_cfg<KIND, T, 64, 1, 1>(st, g, A); break;
+    case 3: launch_tb_cfg<KIND, T, 32, 1, 1>(st, g, A); break;
     default: launch_tb_cfg<KIND, T, 64, 1>(st, g, A); break;
     }
 }
@@ -461,6 +468,56 @@ void jacobi_sweep(hipStream_t st, const FsGrid& g, const float* p, float* np, co
 }
 
 int jacobi_block() { return kT; }
+
+// Which variant wins depends on how the tile counts round against the CU count and on whether the
+// fields live in HBM or in the Infinity Cache (64-byte aligned output rows: 512^3 8.72 -> 8.37 ms
+// per 80 sweeps, 448^3 5.08 -> 6.32), so it is measured on the grid itself: a few passes each.
+void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float* div)
+{
+    g.jacobi_tile = 0;
+    // what a slab's interior launch produces: planes whose T-sweep cone stays inside the owned
+    // planes (a pass may only store planes it holds T input planes around, except at a wall)
+    const int out_lo = g.z0 + (g.wall_lo ? 0 : kT), out_hi = g.z0 + g.nzl - (g.wall_hi ? 0 : kT);
+    if (!can_block(g) || out_hi <= out_lo) return;
+    if (const char* e = getenv("FS_JACOBI_TUNE"))
+        if (atoi(e) == 0) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return;
+    if (hipEventCreate(&b) != hipSuccess) {
+        (void)hipEventDestroy(a);
+        return;
+    }
+    const bool small = (long)g.nx * g.ny < 224L * 224L;
+    const int cand_small[] = {1, 3}, cand_large[] = {0, 2, 3, 1};
+    const int* cand = small ? cand_small : cand_large;
+    const int ncand = small ? 2 : 4;
+    float best = -1.f;
+    int best_cfg = -1;
+    for (int c = 0; c < ncand; ++c) {
+        g.jacobi_tile = cand[c] + 1;
+        float *x = p, *y = np;
+        auto pass = [&] {
+            launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
+            float* t = x; x = y; y = t;
+        };
+        pass();
+        (void)hipEventRecord(a, st);
+        for (int i = 0; i < 4; ++i) pass();
+        (void)hipEventRecord(b, st);
+        float ms = 0.f;
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) {
+            best_cfg = -1;
+            break;
+        }
+        if (best < 0.f || ms < best) {
+            best = ms;
+            best_cfg = cand[c];
+        }
+    }
+    g.jacobi_tile = best_cfg >= 0 ? best_cfg + 1 : 0;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+}
 
 bool jacobi_can_block(const FsGrid& g) { return can_block(g); }
 

@@ -784,6 +784,8 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                 }
             }
         }
+        // all fields are zero here: let the blocked Jacobi kernel pick its tile variant on this grid
+        fsk::jacobi_autotune(s->st, g, s->f.p, s->f.np, s->f.div);
         // zero state: every ghost plane already equals its neighbour's owned plane
         s->vel_ghost_ok = s->scal_ghost_ok = true;
         s->p_ghost = g.ghost;

@@ -94,11 +94,11 @@ def test_jacobi_random(fs, oracle, dims, sweeps):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 @pytest.mark.parametrize("dims", [(132, 70, 23), (64, 61, 9), (60, 124, 40), (8, 1, 5), (196, 130, 12)])
 def test_jacobi_tile_variants(fs, oracle, dims, cfg, monkeypatch):
-    """Both tile shapes of the blocked kernel (64- and 32-row tiles) on grids with several tiles
-    per direction, tile edges that coincide with walls, walls in mid-tile and single-tile grids;
+    """The tile variants of the blocked kernel (64- and 32-row tiles; output rows of 56 cells or
+    of 48 cells on 64-byte boundaries) on grids with several tiles per direction, tile edges that coincide with walls, walls in mid-tile and single-tile grids;
     8 and 6 sweeps (two fused passes; a fused pass plus two single sweeps)."""
     monkeypatch.setenv("FS_JACOBI_CFG", str(cfg))
     nx, ny, nz = dims
@@ -310,7 +310,7 @@ def test_vorticity_confinement_rejected_on_slabs(fs):
     assert rc == -1 and b"single-GPU" in L.fs_last_error()
 
 
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [0, 1, 2])
 def test_jacobi_division_on_hard_inputs(fs, oracle, cfg, monkeypatch):
     """The fused kernel divides by 6 through a binary64 multiply; the oracle uses the true
     division.  Inputs chosen to land on the hard cases: quotients that are exact ties of the
