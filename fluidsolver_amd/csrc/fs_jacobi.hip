@@ -21,6 +21,7 @@
 #include "fs_kernels.h"
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
 
@@ -418,6 +419,7 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
         }
     }
     A.lz = cdiv(nout, chunks);
+    if (g.jacobi_lz > 0) A.lz = min(nout, g.jacobi_lz);
     if (tb_chunk_planes() > 0) A.lz = min(nout, tb_chunk_planes());
     A.chunks1 = cdiv(n1, A.lz);      // chunks never straddle the two ranges
     chunks = A.chunks1 + cdiv(n2, A.lz);
@@ -471,50 +473,79 @@ int jacobi_block() { return kT; }
 
 // Which variant wins depends on how the tile counts round against the CU count and on whether the
 // fields live in HBM or in the Infinity Cache (64-byte aligned output rows: 512^3 8.72 -> 8.37 ms
-// per 80 sweeps, 448^3 5.08 -> 6.32), so it is measured on the grid itself: a few passes each.
+// per 80 sweeps, 448^3 5.08 -> 6.32), and the cost model of the z chunking does not see that ~200
+// workgroups already saturate the memory system (512^3, aligned rows: 2 chunks 7.85 ms, the
+// model's 7 chunks 8.35), so both are measured on the grid itself: a few passes per candidate.
 void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float* div)
 {
     g.jacobi_tile = 0;
+    g.jacobi_lz = 0;
     // what a slab's interior launch produces: planes whose T-sweep cone stays inside the owned
     // planes (a pass may only store planes it holds T input planes around, except at a wall)
     const int out_lo = g.z0 + (g.wall_lo ? 0 : kT), out_hi = g.z0 + g.nzl - (g.wall_hi ? 0 : kT);
     if (!can_block(g) || out_hi <= out_lo) return;
-    if (const char* e = getenv("FS_JACOBI_TUNE"))
+    bool verbose = false;   // FS_JACOBI_TUNE=2 prints the readings
+    if (const char* e = getenv("FS_JACOBI_TUNE")) {
         if (atoi(e) == 0) return;
+        verbose = atoi(e) == 2;
+    }
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess) return;
     if (hipEventCreate(&b) != hipSuccess) {
         (void)hipEventDestroy(a);
         return;
     }
+    const int nout = out_hi - out_lo;
     const bool small = (long)g.nx * g.ny < 224L * 224L;
     const int cand_small[] = {1, 3}, cand_large[] = {0, 2, 3, 1};
     const int* cand = small ? cand_small : cand_large;
     const int ncand = small ? 2 : 4;
-    float best = -1.f;
-    int best_cfg = -1;
-    for (int c = 0; c < ncand; ++c) {
-        g.jacobi_tile = cand[c] + 1;
-        float *x = p, *y = np;
-        auto pass = [&] {
-            launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
-            float* t = x; x = y; y = t;
-        };
-        pass();
-        (void)hipEventRecord(a, st);
-        for (int i = 0; i < 4; ++i) pass();
-        (void)hipEventRecord(b, st);
-        float ms = 0.f;
-        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) {
-            best_cfg = -1;
-            break;
-        }
-        if (best < 0.f || ms < best) {
-            best = ms;
-            best_cfg = cand[c];
+    const int chunk_counts[] = {0, 1, 2, 3, 4, 5, 6, 8};   // 0: the cost model's choice
+    // short passes need more repetitions for a stable reading
+    const int timed = (long)g.nx * g.ny * nout >= 384L * 384L * 384L ? 3 : 12;
+    // the rule's variant with the model's chunking is the reference: another candidate has to
+    // beat it by more than the noise of these short measurements to be taken
+    const int rule_cfg = small ? 1 : 0;
+    float best = -1.f, rule_ms = -1.f;
+    int best_cfg = -1, best_lz = 0;
+    bool failed = false;
+    for (int c = 0; c < ncand && !failed; ++c) {
+        for (int cc : chunk_counts) {
+            const int lz = cc ? cdiv(nout, cc) : 0;
+            if (cc && lz < 2 * kT) continue;   // chunks shorter than their ramp never win
+            g.jacobi_tile = cand[c] + 1;
+            g.jacobi_lz = lz;
+            float *x = p, *y = np;
+            auto pass = [&] {
+                launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
+                float* t = x; x = y; y = t;
+            };
+            pass();
+            (void)hipEventRecord(a, st);
+            for (int i = 0; i < timed; ++i) pass();
+            (void)hipEventRecord(b, st);
+            float ms = 0.f;
+            if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) {
+                failed = true;
+                break;
+            }
+            if (verbose) fprintf(stderr, "jacobi_autotune: variant %d, %d planes per chunk: %.1f us per pass\n",
+                                 cand[c], lz, 1e3f * ms / timed);
+            if (cand[c] == rule_cfg && lz == 0) rule_ms = ms;
+            if (best < 0.f || ms < best) {
+                best = ms;
+                best_cfg = cand[c];
+                best_lz = lz;
+            }
         }
     }
-    g.jacobi_tile = best_cfg >= 0 ? best_cfg + 1 : 0;
+    if (failed || best_cfg < 0 || (rule_ms > 0.f && best > 0.97f * rule_ms)) {
+        g.jacobi_tile = 0;
+        g.jacobi_lz = 0;
+    } else {
+        g.jacobi_tile = best_cfg + 1;
+        g.jacobi_lz = best_lz;
+    }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
 }

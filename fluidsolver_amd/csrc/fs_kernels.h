@@ -22,6 +22,7 @@ struct FsGrid {
     int wall_lo;      // 1 if z0 is the global z = 0 wall
     int wall_hi;      // 1 if z0 + nzl is the global z = nz wall
     int jacobi_tile;  // 1 + tile variant of the blocked Jacobi kernel chosen for this grid, 0 = by rule
+    int jacobi_lz;    // planes per z chunk of a blocked pass chosen for this grid, 0 = by the cost model
 };
 
 struct FsFields {
@@ -92,8 +93,8 @@ bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, con
                  int zout2_hi = 0);
 bool jacobi_can_block(const FsGrid& g);
 // Times the tile variants of the blocked kernel on this grid (p, np, div must hold zeros: the
-// passes then leave them zero) and records the fastest in g.jacobi_tile.  All variants return the
-// same values, so the choice only affects speed.
+// passes then leave them zero) and their z chunking, and records the fastest in g.jacobi_tile /
+// g.jacobi_lz.  All variants return the same values, so the choice only affects speed.
 void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float* div);
 int jacobi_block();   // sweeps fused per pass
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
