@@ -23,6 +23,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <utility>
 
 #pragma clang fp contract(off)
@@ -476,14 +479,13 @@ int jacobi_block() { return kT; }
 // per 80 sweeps, 448^3 5.08 -> 6.32), and the cost model of the z chunking does not see that ~200
 // workgroups already saturate the memory system (512^3, aligned rows: 2 chunks 7.85 ms, the
 // model's 7 chunks 8.35), so both are measured on the grid itself: a few passes per candidate.
-void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float* div)
+// The timing loop: `pass()` launches one pass with g's current jacobi_tile / jacobi_lz over `nout`
+// output planes.  Leaves the winner in g (zeros = the rule and the cost model).
+template <class Pass>
+void tune_tb(hipStream_t st, FsGrid& g, int nout, const char* what, Pass&& pass)
 {
     g.jacobi_tile = 0;
     g.jacobi_lz = 0;
-    // what a slab's interior launch produces: planes whose T-sweep cone stays inside the owned
-    // planes (a pass may only store planes it holds T input planes around, except at a wall)
-    const int out_lo = g.z0 + (g.wall_lo ? 0 : kT), out_hi = g.z0 + g.nzl - (g.wall_hi ? 0 : kT);
-    if (!can_block(g) || out_hi <= out_lo) return;
     bool verbose = false;   // FS_JACOBI_TUNE=2 prints the readings
     if (const char* e = getenv("FS_JACOBI_TUNE")) {
         if (atoi(e) == 0) return;
@@ -495,7 +497,6 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
         (void)hipEventDestroy(a);
         return;
     }
-    const int nout = out_hi - out_lo;
     const bool small = (long)g.nx * g.ny < 224L * 224L;
     const int cand_small[] = {1, 3}, cand_large[] = {0, 2, 3, 1};
     const int* cand = small ? cand_small : cand_large;
@@ -515,11 +516,6 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
             if (cc && lz < 2 * kT) continue;   // chunks shorter than their ramp never win
             g.jacobi_tile = cand[c] + 1;
             g.jacobi_lz = lz;
-            float *x = p, *y = np;
-            auto pass = [&] {
-                launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
-                float* t = x; x = y; y = t;
-            };
             pass();
             (void)hipEventRecord(a, st);
             for (int i = 0; i < timed; ++i) pass();
@@ -529,8 +525,8 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
                 failed = true;
                 break;
             }
-            if (verbose) fprintf(stderr, "jacobi_autotune: variant %d, %d planes per chunk: %.1f us per pass\n",
-                                 cand[c], lz, 1e3f * ms / timed);
+            if (verbose) fprintf(stderr, "%s %dx%dx%d: variant %d, %d planes per chunk: %.1f us per pass\n", what,
+                                 g.nx, g.ny, nout, cand[c], lz, 1e3f * ms / timed);
             if (cand[c] == rule_cfg && lz == 0) rule_ms = ms;
             if (best < 0.f || ms < best) {
                 best = ms;
@@ -548,6 +544,21 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
     }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
+}
+
+void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float* div)
+{
+    g.jacobi_tile = 0;
+    g.jacobi_lz = 0;
+    // what a slab's interior launch produces: planes whose T-sweep cone stays inside the owned
+    // planes (a pass may only store planes it holds T input planes around, except at a wall)
+    const int out_lo = g.z0 + (g.wall_lo ? 0 : kT), out_hi = g.z0 + g.nzl - (g.wall_hi ? 0 : kT);
+    if (!can_block(g) || out_hi <= out_lo) return;
+    float *x = p, *y = np;
+    tune_tb(st, g, out_hi - out_lo, "jacobi_autotune", [&] {
+        launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
+        float* t = x; x = y; y = t;
+    });
 }
 
 bool jacobi_can_block(const FsGrid& g) { return can_block(g); }
@@ -582,6 +593,22 @@ bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const f
     g.wall_lo = g.wall_hi = 1;
     const bool aligned = (((uintptr_t)rhs | (uintptr_t)zin | (uintptr_t)zout) & 15u) == 0;
     if (!can_block(g) || !aligned || (phases != 2 && phases != 4)) return false;
+    // tile variant and chunking of a level: timed the first time a level of these dimensions is
+    // smoothed (the pass is repeated from the same input into the same output, which changes
+    // nothing), then remembered
+    {
+        static std::mutex mu;
+        static std::map<std::tuple<int, int, int>, std::pair<int, int>> tuned;
+        std::lock_guard<std::mutex> lock(mu);
+        const auto key = std::make_tuple(nx, ny, nz);
+        auto it = tuned.find(key);
+        if (it == tuned.end()) {
+            tune_tb(st, g, nz, "rbgs_autotune", [&] { launch_tb<4, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz); });
+            it = tuned.emplace(key, std::make_pair(g.jacobi_tile, g.jacobi_lz)).first;
+        }
+        g.jacobi_tile = it->second.first;
+        g.jacobi_lz = it->second.second;
+    }
     if (zin_is_zero) {
         if (phases == 4) launch_tb<4, kRbgsZero>(st, g, zin, zout, rhs, 0, nz, 0, nz);
         else launch_tb<2, kRbgsZero>(st, g, zin, zout, rhs, 0, nz, 0, nz);
