@@ -141,6 +141,46 @@ __global__ void k_gradient(float* __restrict__ ux, float* __restrict__ uy, float
     }
 }
 
+// The same with four cells along x per thread (nx % 4 == 0): thread (x4, j, k) owns faces
+// 4*x4 .. 4*x4+3 of ux, uy, uz; the thread of the last quad also owns the wall face i = nx of ux.
+// Every face evaluates the expression of k_gradient on the same clamped samples.
+__global__ void k_gradient4(float* __restrict__ ux, float* __restrict__ uy, float* __restrict__ uz,
+                            const float* __restrict__ p, int nx, int ny, int nz, int pitch, int plane,
+                            int zb, int ze_cells)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = zb + blockIdx.z;
+    const int i = 4 * x4;
+    if (i >= nx || j > ny) return;
+    const int jc = min(j, ny - 1), kc = min(k, nz - 1);
+    const f4 pc = *(const f4*)(p + i + jc * pitch + kc * plane);
+    const int o = i + j * pitch + k * plane;
+    if (j < ny && k < ze_cells) {
+        const float pl = p[max(i - 1, 0) + jc * pitch + kc * plane];
+        f4 u = *(f4*)(ux + o);
+        u.x -= pc.x - pl;
+        u.y -= pc.y - pc.x;
+        u.z -= pc.z - pc.y;
+        u.w -= pc.w - pc.z;
+        *(f4*)(ux + o) = u;
+        if (i + 4 == nx) ux[o + 4] -= pc.w - pc.w;   // face i = nx: both clamped samples are p[nx-1]
+    }
+    if (k < ze_cells) {
+        const f4 pbo = *(const f4*)(p + i + max(j - 1, 0) * pitch + kc * plane);
+        f4 u = *(f4*)(uy + o);
+        u -= pc - pbo;
+        *(f4*)(uy + o) = u;
+    }
+    if (j < ny) {
+        const f4 pbh = *(const f4*)(p + i + jc * pitch + max(k - 1, 0) * plane);
+        f4 u = *(f4*)(uz + o);
+        u -= pc - pbh;
+        *(f4*)(uz + o) = u;
+    }
+}
+
 // ---------------------------------------------------------------- residual
 
 constexpr int kResBlock = 256;
@@ -243,6 +283,12 @@ void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, co
 void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* p)
 {
     ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
+    if (g.nx % 4 == 0) {
+        hipLaunchKernelGGL(k_gradient4, tile_grid(g.nx / 4, g.ny + 1, g.nzl + 1), kTile, 0, st,
+                           ux - zoff, uy - zoff, uz - zoff, p - zoff, g.nx, g.ny, g.nz, g.pitch, g.plane,
+                           g.z0, g.z0 + g.nzl);
+        return;
+    }
     hipLaunchKernelGGL(k_gradient, tile_grid(g.nx + 1, g.ny + 1, g.nzl + 1), kTile, 0, st,
                        ux - zoff, uy - zoff, uz - zoff, p - zoff, g.nx, g.ny, g.nz, g.pitch, g.plane,
                        g.z0, g.z0 + g.nzl);
