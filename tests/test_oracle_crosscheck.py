@@ -1,0 +1,214 @@
+"""A second, independent transcription of the advection (numpy float32 scalars, plain loops) against
+the C oracle, bit for bit.
+
+The reference holds no vectors for this path, so the oracle is pinned by literal fidelity only.
+This file restates the same reference lines a second time, in another language and without
+looking at the C code's structure: CuSolver/Source/Solver.cu sample/cg_sample :30-42, trilerp
+:52-113, RK4 :139-161, MacCormack :163-169, SemiLagKernel :370-403, Solver::Advect :1145-1165;
+CuSolver/Include/Math.cuh lerp :57-60 and the float3 operators :80-118.  Two transcriptions that
+agree on random fields (negative coordinates, traces leaving the box included) leave little room
+for a slip in association order, truncation or the zero-outside rule in either.
+"""
+import math
+
+import numpy as np
+import pytest
+
+F = np.float32
+
+
+def cg_sample(field, x, y, z):   # :37-42, field indexed [z, y, x]
+    dz, dy, dx = field.shape
+    if x < 0 or x >= dx or y < 0 or y >= dy or z < 0 or z >= dz:
+        return F(0)
+    return field[z, y, x]
+
+
+def lerp(a, b, s):   # Math.cuh:57-60
+    return F(F(a * F(F(1) - s)) + F(b * s))
+
+
+def split(c):   # :58-82 for one axis
+    i = int(c)                                   # truncation toward zero
+    f = F(c - F(math.floor(c)))
+    if float(c) < -1e-6:                         # float promoted to double against the literal
+        i -= 1
+        f = F(c - F(i))
+    return i, f
+
+
+def trilerp(field, pos, off):   # :52-113 with b_minmax_sampe = false
+    ix, fx = split(F(pos[0] - off[0]))
+    iy, fy = split(F(pos[1] - off[1]))
+    iz, fz = split(F(pos[2] - off[2]))
+    a = cg_sample(field, ix, iy, iz)
+    b = cg_sample(field, ix + 1, iy, iz)
+    c = cg_sample(field, ix, iy + 1, iz)
+    d = cg_sample(field, ix + 1, iy + 1, iz)
+    e = cg_sample(field, ix, iy, iz + 1)
+    f = cg_sample(field, ix + 1, iy, iz + 1)
+    g = cg_sample(field, ix, iy + 1, iz + 1)
+    h = cg_sample(field, ix + 1, iy + 1, iz + 1)
+    l1 = lerp(lerp(a, b, fx), lerp(c, d, fx), fy)
+    l2 = lerp(lerp(e, f, fx), lerp(g, h, fx), fy)
+    return lerp(l1, l2, fz)
+
+
+OFF = {0: (F(.5), F(.5), F(.5)), 1: (F(0), F(.5), F(.5)), 2: (F(.5), F(0), F(.5)), 3: (F(.5), F(.5), F(0))}
+
+
+def velocity(ux, uy, uz, pos):   # the three gathers of :142-144
+    return [trilerp(ux, pos, OFF[1]), trilerp(uy, pos, OFF[2]), trilerp(uz, pos, OFF[3])]
+
+
+def rk4(ux, uy, uz, pos, dt):   # :139-161
+    u1 = velocity(ux, uy, uz, pos)
+    h = F(F(0.5) * dt)
+    p1 = [F(pos[q] - F(h * u1[q])) for q in range(3)]
+    u2 = velocity(ux, uy, uz, p1)
+    p2 = [F(pos[q] - F(h * u2[q])) for q in range(3)]
+    u3 = velocity(ux, uy, uz, p2)
+    p3 = [F(pos[q] - F(dt * u3[q])) for q in range(3)]
+    u4 = velocity(ux, uy, uz, p3)
+    out = []
+    for q in range(3):   # pos - dt * (u1 + 2.0 * u2 + 2.0 * u3 + u4) / 6.0, float operators throughout
+        s = F(F(F(u1[q] + F(F(2) * u2[q])) + F(F(2) * u3[q])) + u4[q])
+        out.append(F(pos[q] - F(F(dt * s) / F(6))))
+    return out
+
+
+def maccormack(ux, uy, uz, pos, dt):   # :163-169
+    pred = rk4(ux, uy, uz, pos, dt)
+    refl = rk4(ux, uy, uz, pred, F(-dt))
+    return [F(pred[q] + F(F(pos[q] - refl[q]) / F(2))) for q in range(3)]
+
+
+def semilag(field, ux, uy, uz, dt, direction, mac):   # :370-403
+    out = np.empty_like(field)
+    dz, dy, dx = field.shape
+    o = OFF[direction]
+    for k in range(dz):
+        for j in range(dy):
+            for i in range(dx):
+                pos = [F(F(i) + o[0]), F(F(j) + o[1]), F(F(k) + o[2])]
+                coord = maccormack(ux, uy, uz, pos, dt) if mac else rk4(ux, uy, uz, pos, dt)
+                out[k, j, i] = trilerp(field, coord, o)
+    return out
+
+
+def advect(st, dt, mac):   # Solver::Advect :1145-1165
+    ux, uy, uz = st[0], st[1], st[2]
+    nux = semilag(ux, ux, uy, uz, dt, 1, mac)
+    nuy = semilag(uy, ux, uy, uz, dt, 2, mac)
+    nuz = semilag(uz, ux, uy, uz, dt, 3, mac)
+    T = semilag(st[4], nux, nuy, nuz, dt, 0, mac)      # temperature first, with the NEW velocity
+    rho = semilag(st[3], nux, nuy, nuz, dt, 0, mac)
+    return {0: nux, 1: nuy, 2: nuz, 3: rho, 4: T}
+
+
+@pytest.mark.parametrize("scheme", [1, 0])
+@pytest.mark.parametrize("dims,scale", [((6, 5, 4), 1.5), ((4, 7, 5), 6.0)])
+def test_second_transcription_of_the_advection_agrees_with_the_oracle(oracle, dims, scale, scheme):
+    from conftest import random_fields
+    nx, ny, nz = dims
+    o = oracle.Oracle(oracle.default_params(nx, ny, nz, scheme=scheme))
+    st = random_fields(nx, ny, nz, seed=77 + nx + scheme, vel_scale=scale)
+    for fid, arr in st.items():
+        o.set(fid, arr)
+    o.stage("advect")
+    want = advect(st, F(o.params.dt), scheme == 1)
+    for fid, arr in want.items():
+        got = o.get(fid)
+        assert got.shape == arr.shape
+        assert np.array_equal(got, arr), "field %d: %d of %d differ" % (fid, int((got != arr).sum()), arr.size)
+    o.close()
+
+
+def sample(field, x, y, z):   # :30-34 with Math.cuh minmax :33-39
+    dz, dy, dx = field.shape
+    return field[max(0, min(z, dz - 1)), max(0, min(y, dy - 1)), max(0, min(x, dx - 1))]
+
+
+def trilerp_clamped(field, pos, off):   # :52-113 with b_minmax_sampe = true
+    ix, fx = split(F(pos[0] - off[0]))
+    iy, fy = split(F(pos[1] - off[1]))
+    iz, fz = split(F(pos[2] - off[2]))
+    tap = lambda a, b, c: sample(field, ix + a, iy + b, iz + c)
+    l1 = lerp(lerp(tap(0, 0, 0), tap(1, 0, 0), fx), lerp(tap(0, 1, 0), tap(1, 1, 0), fx), fy)
+    l2 = lerp(lerp(tap(0, 0, 1), tap(1, 0, 1), fx), lerp(tap(0, 1, 1), tap(1, 1, 1), fx), fy)
+    return lerp(l1, l2, fz)
+
+
+def force(uy, T, dt, T_env):   # ForceKernelUy :346-368, launched over the uy faces
+    out = uy.copy()
+    dz, dy, dx = uy.shape
+    for k in range(dz):
+        for j in range(dy):
+            for i in range(dx):
+                pos = [F(F(i) + F(.5)), F(j), F(F(k) + F(.5))]
+                t = trilerp_clamped(T, pos, OFF[0])
+                out[k, j, i] = F(uy[k, j, i] + F(F(t - T_env) * dt))
+    return out
+
+
+def divergence(ux, uy, uz):   # DivergenceKernel :406-423
+    dz, dy, dx = uz.shape[0] - 1, uy.shape[1] - 1, ux.shape[2] - 1
+    out = np.empty((dz, dy, dx), F)
+    for k in range(dz):
+        for j in range(dy):
+            for i in range(dx):
+                ul, ur = sample(ux, i, j, k), sample(ux, i + 1, j, k)
+                ubo, ut = sample(uy, i, j, k), sample(uy, i, j + 1, k)
+                ubh, uf = sample(uz, i, j, k), sample(uz, i, j, k + 1)
+                out[k, j, i] = F(F(F(F(F(ur + uf) + ut) - ul) - ubh) - ubo)
+    return out
+
+
+def jacobi(p, div):   # JacobiKernel :426-443, one sweep
+    out = np.empty_like(p)
+    dz, dy, dx = p.shape
+    for k in range(dz):
+        for j in range(dy):
+            for i in range(dx):
+                pl, pr = sample(p, i - 1, j, k), sample(p, i + 1, j, k)
+                pbo, pt = sample(p, i, j - 1, k), sample(p, i, j + 1, k)
+                pbh, pf = sample(p, i, j, k - 1), sample(p, i, j, k + 1)
+                s = F(F(F(F(F(F(pl + pr) + pbh) + pf) + pbo) + pt) - div[k, j, i])
+                out[k, j, i] = F(s / F(6))
+    return out
+
+
+def gradient(ux, uy, uz, p):   # ApplyGradientUx/Uy/Uz :446-483
+    ox, oy, oz = ux.copy(), uy.copy(), uz.copy()
+    for arr, out, d in ((ux, ox, (1, 0, 0)), (uy, oy, (0, 1, 0)), (uz, oz, (0, 0, 1))):
+        dz, dy, dx = arr.shape
+        for k in range(dz):
+            for j in range(dy):
+                for i in range(dx):
+                    lo = sample(p, i - d[0], j - d[1], k - d[2])
+                    hi = sample(p, i, j, k)
+                    out[k, j, i] = F(arr[k, j, i] - F(hi - lo))
+    return ox, oy, oz
+
+
+def test_second_transcription_of_force_and_projection_agrees_with_the_oracle(oracle):
+    from conftest import random_fields
+    nx, ny, nz = 7, 5, 6
+    o = oracle.Oracle(oracle.default_params(nx, ny, nz, jacobi_iters=5, temperature_env=0.25))
+    st = random_fields(nx, ny, nz, seed=99, vel_scale=2.0)
+    for fid, arr in st.items():
+        o.set(fid, arr)
+    o.stage("force")
+    uy = force(st[1], st[4], F(o.params.dt), F(0.25))
+    assert np.array_equal(o.get(1), uy)
+    o.stage("project")                     # divergence + 5 sweeps (the #if 0 branch of Solver::Project)
+    div = divergence(st[0], uy, st[2])
+    assert np.array_equal(o.get(6), div)
+    p = st[5]
+    for _ in range(5):
+        p = jacobi(p, div)
+    assert np.array_equal(o.get(5), p)
+    o.stage("gradient")
+    gx, gy, gz = gradient(st[0], uy, st[2], p)
+    assert np.array_equal(o.get(0), gx) and np.array_equal(o.get(1), gy) and np.array_equal(o.get(2), gz)
+    o.close()
