@@ -212,3 +212,98 @@ def test_second_transcription_of_force_and_projection_agrees_with_the_oracle(ora
     gx, gy, gz = gradient(st[0], uy, st[2], p)
     assert np.array_equal(o.get(0), gx) and np.array_equal(o.get(1), gy) and np.array_equal(o.get(2), gz)
     o.close()
+
+
+class FlatView:
+    """A vorticity buffer as the reference indexes it: one flat array read with the strides AND
+    clamps of whatever dims the call site passes (sample(), :30-34).  The buffer is
+    (nx+1)(ny+1)(nz+1) zero-initialised floats, the defined-behaviour variant of this build."""
+
+    def __init__(self, flat, dims):
+        self.flat, self.dims = flat, dims
+
+    def sample(self, x, y, z):
+        dx, dy, dz = self.dims
+        x = max(0, min(x, dx - 1)); y = max(0, min(y, dy - 1)); z = max(0, min(z, dz - 1))
+        return self.flat[x + y * dx + z * dx * dy]
+
+
+def trilerp_view(view, pos, off):   # :52-113 with b_minmax_sampe = true on a FlatView
+    ix, fx = split(F(pos[0] - off[0]))
+    iy, fy = split(F(pos[1] - off[1]))
+    iz, fz = split(F(pos[2] - off[2]))
+    tap = lambda a, b, c: view.sample(ix + a, iy + b, iz + c)
+    l1 = lerp(lerp(tap(0, 0, 0), tap(1, 0, 0), fx), lerp(tap(0, 1, 0), tap(1, 1, 0), fx), fy)
+    l2 = lerp(lerp(tap(0, 0, 1), tap(1, 0, 1), fx), lerp(tap(0, 1, 1), tap(1, 1, 1), fx), fy)
+    return lerp(l1, l2, fz)
+
+
+def find_vort(ux, uy, uz, nx, ny, nz):   # FindVortx/y/z :485-525, launched <<<(ny, nz), nx>>> (:1035-1037)
+    size = (nx + 1) * (ny + 1) * (nz + 1)
+    vx, vy, vz = np.zeros(size, F), np.zeros(size, F), np.zeros(size, F)
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                ind = i + j * nx + k * nx * ny
+                vx[ind] = F(F(F(sample(uy, i, j, k) - sample(uy, i, j, k - 1)) - sample(uz, i, j, k)) + sample(uz, i, j - 1, k))
+                vy[ind] = F(F(F(sample(uz, i, j, k) - sample(uz, i - 1, j, k)) - sample(ux, i, j, k)) + sample(ux, i, j, k - 1))
+                vz[ind] = F(F(F(sample(ux, i, j, k) - sample(ux, i, j - 1, k)) - sample(uy, i, j, k)) + sample(uy, i - 1, j, k))
+    return vx, vy, vz
+
+
+def confine(u, direction, vx, vy, vz, nx, ny, nz, coeff):   # ApplyVortConfinement :540-605
+    out = u.copy()
+    dz, dy, dx = u.shape                         # = gridDim.y, gridDim.x, blockDim.x of :1078-1080
+    views = (FlatView(vx, (nx, ny + 1, nz + 1)), FlatView(vy, (nx + 1, ny, nz + 1)), FlatView(vz, (nx + 1, ny + 1, nz)))
+    offs = ((F(.5), F(0), F(0)), (F(0), F(.5), F(0)), (F(0), F(0), F(.5)))
+    o = OFF[direction]
+
+    def vort(pos):
+        return [trilerp_view(views[q], pos, offs[q]) for q in range(3)]
+
+    def norm(pos):
+        a, b, c = vort(pos)
+        return F(np.sqrt(F(F(F(a * a) + F(b * b)) + F(c * c))))
+
+    h = 0.5   # the literals 0.5 of :556-588 are doubles: the sum is rounded when it becomes a float
+    for k in range(dz):
+        for j in range(dy):
+            for i in range(dx):
+                if not (2 < i < dx - 2 and 2 < j < dy - 2 and 2 < k < dz - 2):
+                    continue
+                px, py, pz = F(F(i) + o[0]), F(F(j) + o[1]), F(F(k) + o[2])
+                vt, vbo = norm([px, F(float(py) + h), pz]), norm([px, F(float(py) - h), pz])
+                vr, vl = norm([F(float(px) + h), py, pz]), norm([F(float(px) - h), py, pz])
+                vf, vbh = norm([px, py, F(float(pz) + h)]), norm([px, py, F(float(pz) - h)])
+                vxc, vyc, vzc = vort([px, py, pz])
+                gx, gy, gz = F(vr - vl), F(vt - vbo), F(vf - vbh)
+                s = F(F(F(gx * gx) + F(gy * gy)) + F(gz * gz))
+                n = F(math.sqrt(float(s) + 1e-5))                  # :593, double sqrt, narrowed
+                gx, gy, gz = F(gx / n), F(gy / n), F(gz / n)
+                if direction == 1:
+                    d = F(coeff * F(F(gy * vzc) - F(gz * vyc)))
+                elif direction == 2:
+                    d = F(coeff * F(F(gz * vxc) - F(gx * vzc)))
+                else:
+                    d = F(coeff * F(F(gx * vyc) - F(gy * vxc)))
+                out[k, j, i] = F(u[k, j, i] + d)
+    return out
+
+
+def test_second_transcription_of_the_vorticity_confinement_agrees_with_the_oracle(oracle):
+    from conftest import random_fields
+    nx, ny, nz = 9, 8, 10
+    o = oracle.Oracle(oracle.default_params(nx, ny, nz, vort_confine=1))
+    st = random_fields(nx, ny, nz, seed=123, vel_scale=1.0)
+    for fid, arr in st.items():
+        o.set(fid, arr)
+    o.stage("vorticity")
+    o.stage("confine")
+    vx, vy, vz = find_vort(st[0], st[1], st[2], nx, ny, nz)
+    c = F(o.params.curl_strength)
+    for fid, d in ((0, 1), (1, 2), (2, 3)):
+        want = confine(st[fid], d, vx, vy, vz, nx, ny, nz, c)
+        got = o.get(fid)
+        assert np.array_equal(got, want), "component %d: %d differ" % (fid, int((got != want).sum()))
+        assert not np.array_equal(want, st[fid])
+    o.close()
