@@ -307,3 +307,104 @@ def test_second_transcription_of_the_vorticity_confinement_agrees_with_the_oracl
         assert np.array_equal(got, want), "component %d: %d differ" % (fid, int((got != want).sum()))
         assert not np.array_equal(want, st[fid])
     o.close()
+
+
+def cg_flat(f, off, i, j, k, d):   # cg_sample :37-42 on a flat level array
+    dx, dy, dz = d
+    if i < 0 or i >= dx or j < 0 or j >= dy or k < 0 or k >= dz:
+        return F(0)
+    return f[off + i + j * dx + k * dx * dy]
+
+
+def neibor_sum(f, off, i, j, k, d):   # :44-50, summed left to right
+    s = F(cg_flat(f, off, i - 1, j, k, d) + cg_flat(f, off, i + 1, j, k, d))
+    s = F(s + cg_flat(f, off, i, j - 1, k, d))
+    s = F(s + cg_flat(f, off, i, j + 1, k, d))
+    s = F(s + cg_flat(f, off, i, j, k - 1, d))
+    return F(s + cg_flat(f, off, i, j, k + 1, d))
+
+
+def smooth(r, z, off, phase, d):   # Smooth :848-860: cells with (i+j+k) & 1 == phase, in place
+    dx, dy, dz = d
+    new = {}
+    for k in range(dz):
+        for j in range(dy):
+            for i in range(dx):
+                if ((i + j + k) & 1) == phase:
+                    ind = off + i + j * dx + k * dx * dy
+                    new[ind] = F(F(r[ind] + neibor_sum(z, off, i, j, k, d)) / F(6))
+    for ind, v in new.items():   # one colour only reads the other: order within a launch is immaterial
+        z[ind] = v
+
+
+def restrict(r, z, off, d):   # Restrict :862-877 = SubRestrict :822-834 for phases 0..7 in that order
+    dx, dy, dz = d
+    n = dx * dy * dz
+    for phase in range(8):
+        for ck in range(dz // 2):
+            for cj in range(dy // 2):
+                for ci in range(dx // 2):
+                    i, j, k = ci * 2 + (phase & 1), cj * 2 + ((phase >> 1) & 1), ck * 2 + ((phase >> 2) & 1)
+                    ind = off + i + j * dx + k * dx * dy
+                    res = F(r[ind] - F(F(F(6) * z[ind]) - neibor_sum(z, off, i, j, k, d)))
+                    new_ind = off + n + ci + cj * (dx // 2) + ck * (dx // 2) * (dy // 2)
+                    r[new_ind] = F(float(r[new_ind]) + float(res) * 0.5)    # float += float * double
+
+
+def prolongate(z, off, d):   # :836-846
+    dx, dy, dz = d
+    n = dx * dy * dz
+    for k in range(dz):
+        for j in range(dy):
+            for i in range(dx):
+                c = off + n + (i >> 1) + (j >> 1) * (dx >> 1) + (k >> 1) * (dx >> 1) * (dy >> 1)
+                ind = off + i + j * dx + k * dx * dy
+                z[ind] = F(z[ind] + z[c])
+
+
+def v_cycle(r0, dims, levels, init_steps, bottom_steps):   # MG_Preconditioner :1312-1366
+    nx, ny, nz = dims
+    space, t = 0, nx * ny * nz
+    for _ in range(levels):
+        space += t
+        t //= 8
+    r, z = np.zeros(space, F), np.zeros(space, F)   # "initialize z[l] and r[l] with 0 except r[0]"
+    r[:nx * ny * nz] = r0.reshape(-1)
+    d, off = (nx, ny, nz), 0
+    for l in range(levels - 1):
+        for _ in range(init_steps << l):
+            smooth(r, z, off, 0, d)
+            smooth(r, z, off, 1, d)
+        restrict(r, z, off, d)
+        off += d[0] * d[1] * d[2]
+        d = (d[0] >> 1, d[1] >> 1, d[2] >> 1)
+    for _ in range(bottom_steps):
+        smooth(r, z, off, 0, d)
+        smooth(r, z, off, 1, d)
+    for l in range(levels - 2, -1, -1):
+        d = (d[0] << 1, d[1] << 1, d[2] << 1)
+        off -= d[0] * d[1] * d[2]
+        prolongate(z, off, d)
+        for _ in range(init_steps << l):
+            smooth(r, z, off, 0, d)
+            smooth(r, z, off, 1, d)
+    return r, z
+
+
+def test_second_transcription_of_the_multigrid_v_cycle_agrees_with_the_oracle(oracle):
+    rng = np.random.default_rng(8)
+    dims = (8, 16, 8)
+    r0 = rng.standard_normal((dims[2], dims[1], dims[0])).astype(F)
+    _z0, r_o, z_o = oracle.mg_precondition(r0, dims, levels=3, init_smooth_steps=2, bottom_smooth_steps=5)
+    r_t, z_t = v_cycle(r0, dims, 3, 2, 5)
+    assert np.array_equal(r_o, r_t), "restricted residuals: %d differ" % int((r_o != r_t).sum())
+    assert np.array_equal(z_o, z_t), "corrections: %d differ" % int((z_o != z_t).sum())
+    # ComputeAp :789-799
+    p = rng.standard_normal((4, 5, 6)).astype(F)
+    want = np.empty_like(p)
+    flat = p.reshape(-1)
+    for k in range(4):
+        for j in range(5):
+            for i in range(6):
+                want[k, j, i] = F(F(F(6) * cg_flat(flat, 0, i, j, k, (6, 5, 4))) - neibor_sum(flat, 0, i, j, k, (6, 5, 4)))
+    assert np.array_equal(oracle.apply_a(p), want)
