@@ -9,7 +9,9 @@
  * fixtures for this path and its CUDA source cannot be compiled or run here, so
  * this restatement is "parity unpinned" by upstream data.  It is pinned only by
  * following the reference source expression by expression (citations below, all
- * relative to /root/reference) and by analytic known-answer tests in tests/.
+ * relative to /root/reference), by analytic known-answer tests in tests/ and by a
+ * second transcription of the same reference lines in numpy
+ * (tests/test_oracle_crosscheck.py) that it has to match bit for bit.
  *
  * Arithmetic contract: every expression is evaluated in IEEE binary32 in the
  * association order the reference source spells, with NO fused multiply-add
