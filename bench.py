@@ -16,8 +16,11 @@ step, timed with HIP events on the solver's own stream inside the timed region;
 CPU path upstream) timed on this host on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -60,7 +63,7 @@ def cpu_baseline(iters, sample_n):
         "unit": "cell-updates/s",
         "cores": threads,
         "kind": "port",
-        "sample": "1 step of %d^3, %d Jacobi sweeps (2nd step from the zero state), gcc -O2 "
+        "sample": "1 step of %d^3, %d Jacobi sweeps (the 2nd step from the zero state; the 1st, untimed, pays the page faults), gcc -O2 "
                   "-ffp-contract=off + OpenMP, %.2f s" % (sample_n, iters, dt),
     }
 
@@ -86,26 +89,44 @@ def measured_copy_bandwidth(torch, device):
         return None
 
 
-def load_pmc_traffic(kernel, workload):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass, if one matches."""
+def kernel_source_hash():
+    """Hash of the kernel sources the library is built from.  The counter passes are separate
+    rocprofv3 runs (tools/profile_round.sh), so their summary in profiles/pmc_traffic.json carries
+    the hash of the sources it was measured on; numbers from other sources are not reported."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fluidsolver_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(kernel, workload):
+    """(entry, stale) of a kernel class from the committed rocprofv3 --pmc passes: HBM bytes per
+    launch and wave-level VALU instructions per launch.  stale = measured on other kernel sources."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        e = d.get(kernel, {}).get(workload)
-        return float(e["hbm_bytes_per_launch"]) if e else None
+        e = d.get("kernels", {}).get(kernel, {}).get(workload)
+        return e, d.get("source_hash") != kernel_source_hash()
     except Exception:
-        return None
+        return None, True
 
 
-def load_valu_instructions(kernel):
-    """Wave-level VALU instructions per launch from the committed rocprofv3 --pmc pass (512^3)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)[kernel]["SQ_INSTS_VALU"])
-    except Exception:
-        return None
+# rocprofv3 kernel names of the stages (what `--kernel-trace --stats` lists)
+def rocprof_kernel_name(stage, cfg, scheme, fused_div, slab):
+    mac, halo = ("true" if scheme else "false"), ("true" if slab else "false")
+    if stage == "jacobi":
+        nty = cfg.get("tile_rows", 64)
+        return "k_jacobi_tb<0, 4, %d, 1, %d>" % (nty, cfg.get("aligned_rows", 0))
+    if stage == "advect_velocity":
+        return "k_advect_velocity_lds<DimsNarrow, %s, %s>" % (mac, halo)
+    if stage == "advect_scalars":
+        return "k_advect_scalars_lds<DimsNarrow, %s, %s, %s>" % (mac, halo, "true" if fused_div else "false")
+    return {"gradient": "k_gradient4", "force": "k_force4", "divergence": "k_divergence",
+            "source": "k_source"}.get(stage, stage)
 
 
 def stage_rooflines(prof, cells, steps, iters, n):
@@ -122,13 +143,37 @@ def stage_rooflines(prof, cells, steps, iters, n):
         bpc = BYTES_PER_CELL[name] * (iters if name == "jacobi" else 1)
         gbs = bpc * cells * steps / (ms * 1e-3) / 1e9
         e = {"ms_per_step": ms / steps, "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
-        if name.startswith("advect") and n == 512:
-            insts = load_valu_instructions(name)
-            if insts:
-                e["bound"] = "valu"   # one launch per step: instructions per launch = per step
-                e["valu_issue_frac"] = insts / (ms / steps * 1e-3) / (1024 * 2.4e9 / 2.0)
+        pmc, stale = load_pmc(name, "%d^3" % n)
+        if pmc and not stale:
+            per_step = launches / steps if name == "jacobi" else 1.0
+            e["hbm_traffic_gbs"] = pmc["hbm_bytes_per_launch"] * per_step / (ms / steps * 1e-3) / 1e9
+            e["hbm_traffic_frac"] = e["hbm_traffic_gbs"] / HBM_PEAK_GBS
+        e["limiter"] = "hbm"
+        if name.startswith("advect"):
+            e["limiter"] = "valu issue"
+            if pmc and not stale and pmc.get("SQ_INSTS_VALU"):
+                # one launch per step: instructions per launch = per step
+                e["valu_issue_frac"] = pmc["SQ_INSTS_VALU"] / (ms / steps * 1e-3) / (1024 * 2.4e9 / 2.0)
+                e["valu_insts_per_cell"] = pmc["SQ_INSTS_VALU"] * 64.0 / cells
         out[name] = e
     return out
+
+
+def launch_ranks(n, argv):
+    """Run this script as n ranks under torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1) and return the launcher's exit status.  Rank 0 prints the JSON line on the shared
+    stdout."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("FS_BENCH_DRY_LAUNCH"):   # tests: show the command instead of running it
+        print(json.dumps({"launch": cmd, "torch_imported": "torch" in sys.modules}))
+        return 0
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -141,7 +186,8 @@ def main():
     ap.add_argument("--scheme", type=int, default=1)
     ap.add_argument("--naive-jacobi", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=320)
+    ap.add_argument("--cpu-sample", type=int, default=512,
+                    help="edge of the cube the CPU oracle steps once for cpu_baseline (default: the workload itself)")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = size x size x (size*N) column, strong = size^3 cut into N slabs")
@@ -151,12 +197,16 @@ def main():
     ap.add_argument("--check-every", type=int, default=8)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N`: become the launcher.  Nothing in this
+        # process has touched torch or the GPU; the ranks are fresh children.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
-                         % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
     import fluidsolver_amd as fs
@@ -263,7 +313,10 @@ def main():
             algo_bytes = BYTES_PER_CELL.get(dom, 0.0) * cells_rank * args.steps / max(dom_launches, 1)
         avg_launch_s = dom_ms / max(dom_launches, 1) * 1e-3
         achieved = algo_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic = load_pmc_traffic(dom, "%d^3" % n)
+        pmc, stale = load_pmc(dom, "%d^3" % n)
+        traffic = float(pmc["hbm_bytes_per_launch"]) if pmc and not stale and world == 1 else None
+        cfg = solver.jacobi_config()
+        fused_div = world == 1
         stage_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
         out = {
             "metric": "cell-updates/sec per step (incl. pressure iters)",
@@ -274,7 +327,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": args.scaling if world > 1 else None,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (zero initial state, sphere source every step, no RNG)",
@@ -286,19 +339,35 @@ def main():
             # secondary metric: lattice updates per second of the pressure sweeps alone (per GPU)
             "jacobi_lups": (cells_rank * sweeps_done / (prof["jacobi"][0] * 1e-3)) if prof.get("jacobi", (0, 0))[0] > 0 else None,
             "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, sweeps_done / args.steps, n),
+            "autotune": {"jacobi_tile_variant": cfg["variant"], "jacobi_tile_rows": cfg["tile_rows"],
+                         "jacobi_aligned_rows": cfg["aligned_rows"], "jacobi_planes_per_chunk": cfg["planes_per_chunk"]},
+            "rccl_ranks": solver.comm_ranks if world > 1 else 0,
             "roofline": {
-                "kernel": dom,
+                "stage": dom,
+                "kernel": rocprof_kernel_name(dom, cfg, args.scheme, fused_div, world > 1),
                 "bound": "hbm",
+                # what holds this kernel back in practice (the gather kernels are bound by vector
+                # instruction issue, not by memory; their HBM fraction is reported all the same)
+                "limiter": "valu issue" if dom.startswith("advect") else "hbm",
+                # algorithmic bytes of one launch / its average duration: a temporally blocked
+                # pass is credited 12 B per cell per SWEEP, so this may exceed the peak ...
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                # ... while frac_real prices the bytes the fabric actually moved per launch
+                # (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same kernel sources)
                 "traffic": traffic,
+                "frac_real": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_launch_s > 0 else None,
+                "traffic_source": (None if traffic is None else "profiles/pmc_traffic.json (%s)" % pmc.get("source", "?")),
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": dom_launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
+        if traffic is None and world == 1:
+            out["roofline"]["traffic_note"] = ("no counter pass of these kernel sources is committed"
+                                               if stale else "no counter entry for this workload")
         if args.tolerance > 0:
             out["config"]["tolerance"] = args.tolerance
             out["config"]["check_every"] = args.check_every

@@ -15,6 +15,7 @@ FS_PRESSURE_JACOBI, FS_PRESSURE_MGPCG = 0, 1
 FS_FLAG_NO_GRAPH = 1 << 0
 FS_FLAG_JACOBI_NAIVE = 1 << 1
 FS_FLAG_VORT_CONFINE = 1 << 2
+FS_FLAG_TEST_SELF_PEER = 1 << 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -25,8 +26,9 @@ EXPORTED_SYMBOLS = (
     "fs_stage_divergence",
     "fs_stage_jacobi", "fs_stage_project", "fs_stage_gradient", "fs_density_host",
     "fs_velocity_host", "fs_field_host", "fs_field_host_begin", "fs_field_host_end", "fs_field_size", "fs_field_upload", "fs_field_device",
-    "fs_residual", "fs_last_sweeps", "fs_cg_residual", "fs_last_error", "fs_version",
+    "fs_residual", "fs_residual_noalloc", "fs_last_sweeps", "fs_cg_residual", "fs_last_error", "fs_version",
     "fs_profile_enable", "fs_profile_read", "fs_profile_reset",
+    "fs_comm_unique_id", "fs_create_slab", "fs_slab_info", "fs_comm_ranks", "fs_jacobi_config",
 )
 
 STAGES = ("source", "force", "advect_velocity", "advect_scalars", "divergence", "jacobi", "gradient",
@@ -113,6 +115,9 @@ def load_library():
     L.fs_field_upload.argtypes = [vp, C.c_int, _fp]
     L.fs_field_device.argtypes = [vp, C.c_int, C.POINTER(_fp), C.POINTER(Layout)]
     L.fs_residual.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.fs_residual_noalloc.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.fs_comm_ranks.argtypes = [vp]
+    L.fs_jacobi_config.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
     L.fs_cg_residual.argtypes = [vp, C.POINTER(C.c_float)]
     L.fs_profile_enable.argtypes = [vp, C.c_int]
     L.fs_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
@@ -227,12 +232,17 @@ class Solver:
         """Start an asynchronous read-back of a field (snapshot now, transfer overlaps later steps)."""
         self._check(self._L.fs_field_host_begin(self._handle(), field))
 
+    def local_shape(self, field):
+        """numpy shape (z, y, x) of what the host getters return for a field (a z-slab overrides
+        this: the getters move its own planes only)."""
+        p = self.params
+        return field_shape(field, p.nx, p.ny, p.nz)
+
     def field_end(self, field):
         ptr = self._L.fs_field_host_end(self._handle(), field)
         if not ptr:
             raise FsError(-6, self._L.fs_last_error().decode())
-        p = self.params
-        return np.ctypeslib.as_array(ptr, shape=field_shape(field, p.nx, p.ny, p.nz)).copy()
+        return np.ctypeslib.as_array(ptr, shape=self.local_shape(field)).copy()
 
     def field(self, field):
         """Dense host copy (z, y, x) of a field; synchronises."""
@@ -240,23 +250,19 @@ class Solver:
         ptr = self._L.fs_field_host(h, field)
         if not ptr:
             raise FsError(-2, self._L.fs_last_error().decode())
-        p = self.params
-        shape = field_shape(field, p.nx, p.ny, p.nz)
-        return np.ctypeslib.as_array(ptr, shape=shape).copy()
+        return np.ctypeslib.as_array(ptr, shape=self.local_shape(field)).copy()
 
     def velocity(self, component):
         h = self._handle()
         ptr = self._L.fs_velocity_host(h, component)
         if not ptr:
             raise FsError(-2, self._L.fs_last_error().decode())
-        p = self.params
-        return np.ctypeslib.as_array(ptr, shape=field_shape(FS_UX + component, p.nx, p.ny, p.nz)).copy()
+        return np.ctypeslib.as_array(ptr, shape=self.local_shape(FS_UX + component)).copy()
 
     def upload(self, field, arr):
-        p = self.params
         a = np.ascontiguousarray(arr, dtype=np.float32)
-        if a.shape != field_shape(field, p.nx, p.ny, p.nz):
-            raise ValueError("field %d wants shape %s, got %s" % (field, field_shape(field, p.nx, p.ny, p.nz), a.shape))
+        if a.shape != self.local_shape(field):
+            raise ValueError("field %d wants shape %s, got %s" % (field, self.local_shape(field), a.shape))
         self._check(self._L.fs_field_upload(self._handle(), field, a.ctypes.data_as(_fp)))
 
     def device_field(self, field):
@@ -269,6 +275,22 @@ class Solver:
         out = C.c_double()
         self._check(self._L.fs_residual(self._handle(), which, C.byref(out)))
         return out.value
+
+    def residual_noalloc(self, which=0):
+        """fs_residual through the library's static scratch array (no device allocation)."""
+        out = C.c_double()
+        self._check(self._L.fs_residual_noalloc(self._handle(), which, C.byref(out)))
+        return out.value
+
+    def jacobi_config(self):
+        """{variant, tile_rows, aligned_rows, planes_per_chunk} of the blocked Jacobi passes."""
+        v = [C.c_int() for _ in range(4)]
+        self._check(self._L.fs_jacobi_config(self._handle(), *[C.byref(x) for x in v]))
+        return dict(zip(("variant", "tile_rows", "aligned_rows", "planes_per_chunk"), (x.value for x in v)))
+
+    @property
+    def comm_ranks(self):
+        return self._L.fs_comm_ranks(self._handle())
 
     def profile(self, on=True):
         self._check(self._L.fs_profile_enable(self._handle(), int(on)))

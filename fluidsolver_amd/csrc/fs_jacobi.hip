@@ -563,6 +563,15 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
 
 bool jacobi_can_block(const FsGrid& g) { return can_block(g); }
 
+void jacobi_config(const FsGrid& g, int* variant, int* rows, int* aligned, int* planes_per_chunk)
+{
+    const int v = can_block(g) ? tb_config(g) : -1;
+    *variant = v;
+    *rows = v >= 0 ? kConfigs[v].nty * kConfigs[v].cpt : 0;
+    *aligned = v >= 2 ? 1 : 0;
+    *planes_per_chunk = g.jacobi_lz;
+}
+
 bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
                  int sweeps, int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo, int zout2_hi)
 {

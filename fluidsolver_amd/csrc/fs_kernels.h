@@ -96,6 +96,9 @@ bool jacobi_can_block(const FsGrid& g);
 // passes then leave them zero) and their z chunking, and records the fastest in g.jacobi_tile /
 // g.jacobi_lz.  All variants return the same values, so the choice only affects speed.
 void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float* div);
+// what the blocked passes of this grid run with: tile variant (-1 = the grid cannot block), its
+// tile rows, whether its output rows are 64-byte aligned, planes per z chunk (0 = cost model)
+void jacobi_config(const FsGrid& g, int* variant, int* rows, int* aligned, int* planes_per_chunk);
 int jacobi_block();   // sweeps fused per pass
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
 int jacobi_launches(const FsGrid& g, int sweeps, int naive);
@@ -131,5 +134,13 @@ void vort_confine(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* 
 int residual_partials(const FsGrid& g);
 void residual(hipStream_t st, const FsGrid& g, const float* p, const float* div, double* partial,
               double* out);
+// The same scratch as a file-scope device array, for callers that must not allocate: one copy per
+// GPU, residual_static_rows() partials plus the total.  residual_static_lookup(device) resolves the
+// array's address on `device`, which must be the current device (once per device; later calls
+// return at once); residual_static_scratch hands out the resolved addresses, false if the lookup
+// has not run for that device.
+int residual_static_rows();
+hipError_t residual_static_lookup(int device);
+bool residual_static_scratch(int device, double** partial, double** out);
 
 }  // namespace fsk

@@ -12,6 +12,7 @@
 //   pressure gradient :446-483, residual :442.
 #include "fs_kernels.h"
 
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -233,6 +234,16 @@ k_residual_final(const double* partial, int n, double* out)
     if (threadIdx.x == 0) *out = s;
 }
 
+// Scratch of the residual sum for callers that must not allocate (fs_residual_noalloc): one partial
+// per (y, z) row, then the total.  Every GPU this library runs on holds its own copy of the array
+// (8 MiB) until the process ends.  In host code the name below is only a handle for
+// hipGetSymbolAddress: kernels and copies take the per-device address that call returns.
+constexpr int kStaticRows = 1 << 20;
+static __device__ __align__(256) double scratch[kStaticRows + 32];
+constexpr int kMaxDevices = 64;
+double* g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each device, null = not looked up
+std::mutex g_scratch_mu;
+
 inline dim3 tile_grid(int dx, int dy, int dz) { return dim3(cdiv(dx, 64), cdiv(dy, 4), dz); }
 const dim3 kTile(64, 4, 1);
 
@@ -295,6 +306,36 @@ void gradient(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, 
 }
 
 int residual_partials(const FsGrid& g) { return g.ny * g.nzl; }
+
+int residual_static_rows() { return kStaticRows; }
+
+hipError_t residual_static_lookup(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return e;
+    if (cur != device) return hipErrorInvalidDevice;   // the address is the current device's copy
+    double* ptr = nullptr;
+    e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+
+bool residual_static_scratch(int device, double** partial, double** out)
+{
+    if (device < 0 || device >= kMaxDevices) return false;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    double* ptr = g_scratch_ptr[device];
+    if (!ptr) return false;
+    *partial = ptr;
+    *out = ptr + kStaticRows;
+    return true;
+}
 
 void residual(hipStream_t st, const FsGrid& g, const float* p, const float* div, double* partial,
               double* out)

@@ -21,7 +21,9 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -63,6 +65,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -89,6 +92,7 @@ bool load_rccl(Rccl& r)
     FS_SYM(GetUniqueId, "ncclGetUniqueId")
     FS_SYM(CommInitRank, "ncclCommInitRank")
     FS_SYM(CommDestroy, "ncclCommDestroy")
+    FS_SYM(CommCount, "ncclCommCount")
     FS_SYM(Send, "ncclSend")
     FS_SYM(Recv, "ncclRecv")
     FS_SYM(GroupStart, "ncclGroupStart")
@@ -160,7 +164,7 @@ struct fs_solver {
     void* xctx = nullptr;
     hipStream_t cs = nullptr;         // communication stream
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    bool self_peer = false;           // FS_TEST_SELF_PEER: both neighbours are this rank itself (tests)
+    bool self_peer = false;           // FS_FLAG_TEST_SELF_PEER: both neighbours are this rank itself (tests)
     int xchg_streams = -1;            // FS_XCHG_STREAMS: 1 / 0 force the two-stream / one-stream ordering
     char* h_stage[4] = {};            // pinned: send_lo, recv_lo, send_hi, recv_hi
     size_t h_stage_cap = 0;
@@ -168,6 +172,14 @@ struct fs_solver {
     bool div_fresh = false;           // div holds the divergence of the current velocity
     int p_ghost = 0;                  // valid ghost planes of p on each side
     bool halo_pending = false;        // an exchange is in flight; exchange_wait() orders the compute stream after it
+    // FS_DEBUG_XCHG=1: every operation the exchange code enqueues is followed by a labelled event
+    // ("mark") on its queue; a wait that exceeds the time limit reports, per queue, the last mark
+    // that completed and the first that did not, i.e. which operation heads the stuck queue
+    struct XMark { hipEvent_t ev; const char* what; int xchg; char queue; };
+    int dbg_xchg = 0;
+    int xchg_seq = 0;                 // exchanges begun so far
+    int xchg_timeout_ms = 60000;      // FS_XCHG_TIMEOUT_MS: limit of a host-side wait inside an exchange
+    std::vector<XMark> marks;         // oldest first; completed marks are recycled from the front
     // captured steps: a step only launches kernels whose arguments are the field pointers and
     // constants, so a graph captured for one assignment of the 13 buffers to their roles can be
     // replayed whenever the buffers are in that assignment again (the ping-pong swaps give the
@@ -264,13 +276,98 @@ Seg make_seg(const fs_solver* s, float* base, int n, bool face)
     return g;
 }
 
+// FS_DEBUG_XCHG: label the point both queues have reached.  `what` must be a string literal.
+void xmark(fs_solver* s, hipStream_t q, const char* what)
+{
+    if (!s->dbg_xchg) return;
+    hipEvent_t ev = nullptr;
+    // recycle the oldest mark once it has completed and the list is long
+    if (s->marks.size() >= 64 && hipEventQuery(s->marks.front().ev) == hipSuccess) {
+        ev = s->marks.front().ev;
+        s->marks.erase(s->marks.begin());
+    } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        return;
+    }
+    if (hipEventRecord(ev, q) != hipSuccess) {
+        (void)hipEventDestroy(ev);
+        return;
+    }
+    s->marks.push_back({ev, what, s->xchg_seq, q == s->st ? 's' : 'c'});
+}
+
+const char* ready_str(hipError_t e)
+{
+    return e == hipSuccess ? "complete" : (e == hipErrorNotReady ? "NOT complete" : hipGetErrorString(e));
+}
+
+// What each queue is doing, for the report of a stalled wait.
+void xchg_report(fs_solver* s, const char* where, double waited_s)
+{
+    fprintf(stderr, "[fluidsolver rank %d] %s: waited %.1f s in exchange %d; compute stream %s, communication "
+                    "stream %s, ev_ready %s, ev_done %s\n", s->rank, where, waited_s, s->xchg_seq,
+            ready_str(hipStreamQuery(s->st)), s->cs ? ready_str(hipStreamQuery(s->cs)) : "-",
+            s->ev_ready ? ready_str(hipEventQuery(s->ev_ready)) : "-",
+            s->ev_done ? ready_str(hipEventQuery(s->ev_done)) : "-");
+    for (char queue : {'s', 'c'}) {
+        const fs_solver::XMark *done = nullptr, *head = nullptr;
+        int behind = 0;
+        for (const fs_solver::XMark& m : s->marks) {
+            if (m.queue != queue) continue;
+            if (hipEventQuery(m.ev) == hipSuccess) {
+                if (!head) done = &m;
+            } else {
+                if (!head) head = &m;
+                else ++behind;
+            }
+        }
+        if (!done && !head) continue;
+        fprintf(stderr, "[fluidsolver rank %d]   %s queue: last completed '%s' (exchange %d); head of the queue "
+                        "'%s' (exchange %d), %d marked operations behind it\n", s->rank,
+                queue == 's' ? "compute" : "communication", done ? done->what : "-", done ? done->xchg : -1,
+                head ? head->what : "(empty)", head ? head->xchg : -1, behind);
+    }
+    fflush(stderr);
+}
+
+// hipStreamSynchronize with a time limit: a stalled queue becomes an error with a report of what
+// both queues hold instead of a silent hang.
+int bounded_sync(fs_solver* s, hipStream_t q, const char* where)
+{
+    if (s->xchg_timeout_ms <= 0) {
+        FS_HIP(hipStreamSynchronize(q));
+        return FS_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    double next_report = s->dbg_xchg ? 2.0 : 1e30;
+    for (long spins = 0;; ++spins) {
+        hipError_t e = hipStreamQuery(q);
+        if (e == hipSuccess) return FS_OK;
+        if (e != hipErrorNotReady)
+            return fail(FS_ERR_HIP, "%s: hipStreamQuery failed: %s", where, hipGetErrorString(e));
+        if (spins < 2000) continue;
+        usleep(spins < 20000 ? 20 : 200);
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited >= next_report) {
+            xchg_report(s, where, waited);
+            next_report *= 2.0;
+        }
+        if (waited * 1e3 >= s->xchg_timeout_ms) {
+            xchg_report(s, where, waited);
+            return fail(FS_ERR_COMM, "rank %d: %s did not finish within %d ms (FS_XCHG_TIMEOUT_MS); queue "
+                                     "states are on stderr, FS_DEBUG_XCHG=1 adds the operation at the head of each queue",
+                        s->rank, where, s->xchg_timeout_ms);
+        }
+    }
+}
+
 // Compute-stream work enqueued after exchange_begin() runs concurrently with the transfer (RCCL
 // transport) until exchange_wait() makes the compute stream wait for the received planes.
 int exchange_wait(fs_solver* s)
 {
     if (!s->halo_pending) return FS_OK;
-    s->halo_pending = false;
     FS_HIP(hipStreamWaitEvent(s->st, s->ev_done, 0));
+    s->halo_pending = false;
+    xmark(s, s->st, "wait for the received planes (ev_done)");
     return FS_OK;
 }
 
@@ -290,11 +387,14 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
     const bool lo = !s->g.wall_lo, hi = !s->g.wall_hi;
     const bool two_streams = s->xchg_streams >= 0 ? s->xchg_streams != 0 : s->comm != nullptr;
     hipStream_t q = s->st;
+    ++s->xchg_seq;
     if (two_streams) {
         // the communication stream waits for the producers on the compute stream ...
         q = s->cs;
         FS_HIP(hipEventRecord(s->ev_ready, s->st));
+        xmark(s, s->st, "producers of the planes to send (ev_ready)");
         FS_HIP(hipStreamWaitEvent(q, s->ev_ready, 0));
+        xmark(s, q, "wait for the producers (ev_ready)");
     }
     if (s->comm) {
         Rccl* R = rccl();
@@ -312,11 +412,13 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
             }
         }
         FS_NCCL(R->GroupEnd());
+        xmark(s, q, "ncclSend/ncclRecv group");
     } else {
         // host-staged transport: pack through pinned buffers, let the caller's function move them
         size_t bytes = 0;
         for (int i = 0; i < nseg; ++i) bytes += segs[i].n * sizeof(float);
         if (bytes > s->h_stage_cap) {
+            s->h_stage_cap = 0;   // stays 0 if an allocation below fails: the next call starts over
             for (char*& b : s->h_stage) {
                 if (b) (void)hipHostFree(b);
                 b = nullptr;
@@ -331,7 +433,11 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
             if (hi) FS_HIP(hipMemcpyAsync(s->h_stage[2] + off, segs[i].send_hi, nb, hipMemcpyDeviceToHost, q));
             off += nb;
         }
-        FS_HIP(hipStreamSynchronize(q));
+        xmark(s, q, "copies of the planes to send into pinned memory");
+        {
+            int rc = bounded_sync(s, q, "halo exchange, device-to-host copies");
+            if (rc) return rc;
+        }
         int rc = s->xfn(s->xctx, FS_XCHG_HALO, lo ? s->h_stage[0] : nullptr, lo ? s->h_stage[1] : nullptr,
                         hi ? s->h_stage[2] : nullptr, hi ? s->h_stage[3] : nullptr, bytes);
         if (rc) return fail(FS_ERR_COMM, "rank %d: the exchange callback returned %d", s->rank, rc);
@@ -342,6 +448,7 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
             if (hi) FS_HIP(hipMemcpyAsync(segs[i].recv_hi, s->h_stage[3] + off, nb, hipMemcpyHostToDevice, q));
             off += nb;
         }
+        xmark(s, q, "copies of the received planes into the ghost planes");
     }
     if (two_streams) {
         // ... and the consumers on the compute stream wait for the halos in exchange_wait()
@@ -463,10 +570,12 @@ int run_jacobi(fs_solver* s, int sweeps)
                 // (first on the compute stream: run beside the interior launch, which fills every CU,
                 // they took 180 us instead of 25 and delayed the transfer that waits for them)
                 fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, g.z0, ilo, ihi, z1);
+                xmark(s, s->st, "Jacobi pass, boundary planes");
                 Seg seg = make_seg(s, s->f.np, T, false);
                 rc = exchange_begin(s, &seg, 1);
                 if (rc) return rc;
                 fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, ilo, ihi);
+                xmark(s, s->st, "Jacobi pass, interior planes");
                 std::swap(s->f.p, s->f.np);
                 s->p_ghost = T;
                 launches += 2;
@@ -622,6 +731,8 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                                         "(mg_level %d)", m, p->mg_level);
         if (p->tolerance > 0.f) return fail(FS_ERR_INVALID, "fs_create: convergence mode is for the Jacobi solver");
     }
+    if ((p->flags & FS_FLAG_TEST_SELF_PEER) && !(world > 1 && unique_id))
+        return fail(FS_ERR_INVALID, "fs_create: FS_FLAG_TEST_SELF_PEER is a test hook of RCCL slabs");
     if (world > 1 && (p->flags & FS_FLAG_VORT_CONFINE))
         return fail(FS_ERR_INVALID, "fs_create_slab: FS_FLAG_VORT_CONFINE is single-GPU only (its gathers "
                                     "mix z planes through mismatched strides)");
@@ -646,6 +757,15 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(FS_ERR_NO_DEVICE, "fs_create: device %d is %s; this library holds gfx950 code only",
                     dev, prop.gcnArchName);
+
+    // address of the static residual scratch on this device (fs_residual_noalloc), looked up here
+    // so that the entry point itself never has to
+    {
+        hipError_t e = fsk::residual_static_lookup(dev);
+        if (e != hipSuccess)
+            return fail(FS_ERR_HIP, "fs_create: hipGetSymbolAddress of the static scratch on device %d: %s", dev,
+                        hipGetErrorString(e));
+    }
 
     fs_solver* s = new (std::nothrow) fs_solver;
     if (!s) return fail(FS_ERR_INVALID, "fs_create: out of host memory");
@@ -758,6 +878,8 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
             if (const char* e = getenv("FS_XCHG_STREAMS")) s->xchg_streams = atoi(e) != 0;
+            if (const char* e = getenv("FS_DEBUG_XCHG")) s->dbg_xchg = atoi(e);
+            if (const char* e = getenv("FS_XCHG_TIMEOUT_MS")) s->xchg_timeout_ms = atoi(e);
             if (hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, unique_id ? prio_hi : prio_lo) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming) != hipSuccess) {
@@ -772,10 +894,10 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                 }
                 ncclUniqueId id;
                 std::memcpy(&id, unique_id, sizeof(id));
-                // FS_TEST_SELF_PEER (tests on one GPU): a communicator of this rank alone; the slab
-                // keeps its place in the decomposition but trades planes with itself, which drives
-                // the RCCL calls and the stream ordering without a second device
-                s->self_peer = getenv("FS_TEST_SELF_PEER") != nullptr;
+                // FS_FLAG_TEST_SELF_PEER (tests on one GPU): a communicator of this rank alone; the
+                // slab keeps its place in the decomposition but trades planes with itself, which
+                // drives the RCCL calls and the stream ordering without a second device
+                s->self_peer = (p->flags & FS_FLAG_TEST_SELF_PEER) != 0;
                 ncclResult_t ne = R->CommInitRank(&s->comm, s->self_peer ? 1 : world, id, s->self_peer ? 0 : rank);
                 if (ne != ncclSuccess) {
                     s->comm = nullptr;
@@ -847,14 +969,18 @@ int fs_destroy(fs_solver* s)
 {
     if (!s) return FS_OK;
     (void)hipSetDevice(s->device);
+    // every queue that may still touch a buffer drains before anything is freed (a read-back begun
+    // with fs_field_host_begin and never ended is still writing its pinned buffer)
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->cs) (void)hipStreamSynchronize(s->cs);
+    if (s->copy_st) (void)hipStreamSynchronize(s->copy_st);
     if (s->comm && rccl()) (void)rccl()->CommDestroy(s->comm);
     for (auto& pe : s->ev_pending) {
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);
     }
     for (hipEvent_t e : s->ev_free) (void)hipEventDestroy(e);
+    for (auto& m : s->marks) (void)hipEventDestroy(m.ev);
     for (fs_solver::StepGraph& g : s->graphs) (void)hipGraphExecDestroy(g.exec);
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
     if (s->ev_done) (void)hipEventDestroy(s->ev_done);
@@ -869,7 +995,6 @@ int fs_destroy(fs_solver* s)
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->pool) (void)hipFree(s->pool);
     if (s->vort[0]) (void)hipFree(s->vort[0]);
-    if (s->copy_st) (void)hipStreamSynchronize(s->copy_st);
     if (s->snap) (void)hipFree(s->snap);
     if (s->ev_snap) (void)hipEventDestroy(s->ev_snap);
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
@@ -913,6 +1038,27 @@ int fs_slab_info(const fs_solver* s, int* rank, int* world, int* z0, int* nz_loc
     if (world) *world = s->world;
     if (z0) *z0 = s->g.z0;
     if (nz_local) *nz_local = s->g.nzl;
+    return FS_OK;
+}
+
+int fs_comm_ranks(const fs_solver* s)
+{
+    if (!s) return -1;
+    if (!s->comm) return 0;
+    int n = 0;
+    if (!rccl() || rccl()->CommCount(s->comm, &n) != ncclSuccess) return -1;
+    return n;
+}
+
+int fs_jacobi_config(const fs_solver* s, int* variant, int* tile_rows, int* aligned_rows, int* planes_per_chunk)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    int v, r, a, lz;
+    fsk::jacobi_config(s->g, &v, &r, &a, &lz);
+    if (variant) *variant = v;
+    if (tile_rows) *tile_rows = r;
+    if (aligned_rows) *aligned_rows = a;
+    if (planes_per_chunk) *planes_per_chunk = lz;
     return FS_OK;
 }
 
@@ -1198,7 +1344,12 @@ int fs_sync(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     FS_HIP(hipSetDevice(s->device));
-    FS_HIP(hipStreamSynchronize(s->st));
+    if (s->world > 1) {
+        int rc = bounded_sync(s, s->st, "fs_sync");
+        if (rc) return rc;
+    } else {
+        FS_HIP(hipStreamSynchronize(s->st));
+    }
     return check_flag(s);
 }
 
@@ -1418,6 +1569,33 @@ int fs_residual(fs_solver* s, int which, double* out)
                                   "(the last sweeps ran as one fused multi-sweep pass)");
     FS_HIP(hipSetDevice(s->device));
     return residual_sync(s, which == 1, out);
+}
+
+int fs_residual_noalloc(fs_solver* s, int which, double* out)
+{
+    if (!s || !out || (which != 0 && which != 1))
+        return fail(FS_ERR_INVALID, "fs_residual_noalloc: bad argument");
+    if (s->world > 1)
+        return fail(FS_ERR_STATE, "fs_residual_noalloc: single-GPU solvers only (a z-slab needs a halo "
+                                  "exchange and an all-reduce first)");
+    if (which == 1 && !s->prev_held)
+        return fail(FS_ERR_STATE, "fs_residual_noalloc: the iterate before the last sweep is not held "
+                                  "(the last sweeps ran as one fused multi-sweep pass)");
+    const long long rows = (long long)s->g.ny * s->g.nzl;
+    if (rows > fsk::residual_static_rows())
+        return fail(FS_ERR_INVALID, "fs_residual_noalloc: ny * nz = %lld rows exceed the %d rows of the static "
+                                    "scratch; use fs_residual", rows, fsk::residual_static_rows());
+    FS_HIP(hipSetDevice(s->device));
+    double *partial = nullptr, *total = nullptr;
+    if (!fsk::residual_static_scratch(s->device, &partial, &total))
+        return fail(FS_ERR_STATE, "fs_residual_noalloc: no static scratch address for device %d", s->device);
+    // every partial the final kernel reads is written by this call; nothing has to start at zero
+    fsk::residual(s->st, s->g, which == 1 ? s->f.np : s->f.p, s->f.div, partial, total);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipMemcpyAsync(s->h_res, total, sizeof(double), hipMemcpyDeviceToHost, s->st));
+    FS_HIP(hipStreamSynchronize(s->st));
+    *out = *s->h_res;
+    return FS_OK;
 }
 
 }  // extern "C"

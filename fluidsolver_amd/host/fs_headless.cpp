@@ -10,12 +10,14 @@
 int main(int argc, char** argv)
 {
 	int frames = argc > 1 ? std::atoi(argv[1]) : 10;
-	// second argument "shipped": the reference's compiled-in configuration (MGPCG + confinement)
-	bool shipped = argc > 2 && std::string(argv[2]) == "shipped";
+	// default: the configuration the reference is compiled with (MGPCG + vorticity confinement),
+	// which is also the class's default; second argument "jacobi": the Jacobi branch of
+	// Solver::Project without confinement
+	bool jacobi = argc > 2 && std::string(argv[2]) == "jacobi";
 	Solver solver = Solver();
-	if (shipped) {
-		solver.SetMultigridSolver(true);
-		solver.SetVorticityConfinement(true);
+	if (jacobi) {
+		solver.SetMultigridSolver(false);
+		solver.SetVorticityConfinement(false);
 	}
 	solver.Initialize();
 	solver.Update();

@@ -131,21 +131,8 @@ class SlabSolver(Solver):
         nz = self.nz_local + (1 if field == FS_UZ else 0)
         return (nz,) + _capi.field_shape(field, p.nx, p.ny, p.nz)[1:]
 
-    def field(self, field):
-        """Dense host copy of the LOCAL planes of a field."""
-        ptr = self._L.fs_field_host(self._handle(), field)
-        if not ptr:
-            raise FsError(-2, self._L.fs_last_error().decode())
-        return np.ctypeslib.as_array(ptr, shape=self.local_shape(field)).copy()
-
-    def velocity(self, component):
-        return self.field(_capi.FS_UX + component)
-
-    def upload(self, field, arr):
-        a = np.ascontiguousarray(arr, dtype=np.float32)
-        if a.shape != self.local_shape(field):
-            raise ValueError("field %d wants local shape %s, got %s" % (field, self.local_shape(field), a.shape))
-        self._check(self._L.fs_field_upload(self._handle(), field, a.ctypes.data_as(C.POINTER(C.c_float))))
+    # field(), field_end(), velocity() and upload() of the base class size their arrays with
+    # local_shape(), so on a slab they move the LOCAL planes
 
     def upload_global(self, field, arr):
         """Take this rank's planes out of a GLOBAL (z, y, x) array."""

@@ -65,20 +65,25 @@ public:
 	float* GetDensityField();
 	/* new: velocity component c = 0,1,2 -> ux (Nx+1,Ny,Nz), uy (Nx,Ny+1,Nz), uz (Nx,Ny,Nz+1) */
 	float* GetVelocityField(int c);
-	/* new: number of Jacobi sweeps per step (reference max_iter, Solver.h:68); call before Initialize */
+	/* new: iteration limit of the pressure solve = Jacobi sweeps per step on the Jacobi branch
+	   (reference max_iter, Solver.h:68); call before Initialize */
 	void SetJacobiIterations(int iters) { jacobi_iters = iters; }
-	/* new: vorticity confinement as in the shipped reference build (Solver.cu:13 VORT_CONFINE 1,
-	   curl_strength Solver.h:73), in its defined-behaviour variant (see FS_FLAG_VORT_CONFINE in
-	   fluidsolver.h); off by default; call before Initialize */
+	/* The defaults are the configuration the reference is compiled with (Solver.cu:10-15: MGPCG 1,
+	   VORT_CONFINE 1; max_iter 30, curl_strength 0.1, Solver.h:68,73), so a caller that only
+	   knows Initialize / Update / GetDensityField gets the simulation the reference ships.  The
+	   setters below (new; call before Initialize) select the other compile-time branches. */
+	/* vorticity confinement (Solver.cu:13, 1035-1037, 1078-1080), in its defined-behaviour variant
+	   (see FS_FLAG_VORT_CONFINE in fluidsolver.h); on by default */
 	void SetVorticityConfinement(bool on, float strength = 0.1f) { vort_confine = on; curl_strength = strength; }
-	/* new: the shipped reference build solves the pressure with MGPCG (Solver.cu:10, 1190-1192);
-	   false (default) = the Jacobi branch (Solver.cu:1178-1189); call before Initialize */
+	/* true (default) = the MGPCG pressure solve the reference enables (Solver.cu:10, 1190-1192; every
+	   grid dimension must be a multiple of 8); false = the Jacobi branch it compiles out
+	   (Solver.cu:1178-1189), jacobi_iters sweeps per step */
 	void SetMultigridSolver(bool on) { mgpcg = on; }
 
 private:
 	fs_solver* handle = nullptr;
 	int jacobi_iters = 30;
-	bool vort_confine = false;
-	bool mgpcg = false;
+	bool vort_confine = true;
+	bool mgpcg = true;
 	float curl_strength = 0.1f;
 };

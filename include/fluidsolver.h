@@ -62,7 +62,12 @@ enum {
        their allocation (Solver.cu:556-558 against :894-896); this build gives the same index
        arithmetic arrays of (nx+1)(ny+1)(nz+1) zero-initialised floats, so every read is defined.
        Single GPU only. */
-    FS_FLAG_VORT_CONFINE = 1 << 2
+    FS_FLAG_VORT_CONFINE = 1 << 2,
+    /* Test hook, RCCL slabs only: the slab keeps its place in the decomposition but its RCCL
+       communicator holds this rank alone and both neighbours are the rank itself, so one GPU can
+       drive ncclSend/ncclRecv and the stream ordering.  The results are NOT those of the
+       decomposed grid; never set it in a real multi-rank run. */
+    FS_FLAG_TEST_SELF_PEER = 1 << 3
 };
 
 /*
@@ -144,6 +149,14 @@ FS_API int fs_comm_unique_id(void* id /* FS_UNIQUE_ID_BYTES */);
 FS_API int fs_create_slab(const fs_params* p, int rank, int world, const void* unique_id,
                           fs_exchange_fn fn, void* ctx, fs_solver** out);
 FS_API int fs_slab_info(const fs_solver* s, int* rank, int* world, int* z0, int* nz_local);
+/* ranks of the RCCL communicator the slab exchanges over (ncclCommCount); 0 = no communicator
+   (single GPU or host-staged transport), -1 = error */
+FS_API int fs_comm_ranks(const fs_solver* s);
+/* What the temporally blocked Jacobi passes of this solver run with (chosen by timing at creation,
+   no counterpart in the reference): tile variant 0..3 (-1 = this grid takes single sweeps only),
+   rows per tile, whether output rows are 64-byte aligned, planes per z chunk (0 = cost model). */
+FS_API int fs_jacobi_config(const fs_solver* s, int* variant, int* tile_rows, int* aligned_rows,
+                            int* planes_per_chunk);
 
 /* -- stepping: replaces Solver::Update -> UpdateCuda (Solver.cu:1009-1114, 1132-1137)
       with VORT_CONFINE off and Project() on its Jacobi branch (Solver.cu:1178-1189) -- */
@@ -195,6 +208,17 @@ FS_API int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layo
       i.e. when the last sweep ran on its own (sweep count not a multiple of 4, or
       FS_FLAG_JACOBI_NAIVE), else FS_ERR_STATE. -- */
 FS_API int fs_residual(fs_solver* s, int which, double* out);
+/* fs_residual for callers that must not allocate device memory (code under HIP graph capture
+   elsewhere in the process, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+   in the reference.  Same arguments, result and synchronisation as fs_residual, but the partial
+   sums live in a file-scope device array of the library (FS_NOALLOC_MAX_ROWS partials + the total,
+   8 MiB per GPU, held until the process ends) instead of the solver's own scratch buffer, and the
+   call makes no hipMalloc / hipFree / pinned allocation.  Limits: single-GPU solvers (not z-slabs:
+   FS_ERR_STATE) with ny * nz <= FS_NOALLOC_MAX_ROWS (else FS_ERR_INVALID).  All solvers on one GPU
+   share that GPU's array: calls that overlap in time on one GPU race; calls on one solver, or on
+   several solvers from one thread, are ordered by the synchronisation at the end of each call. */
+#define FS_NOALLOC_MAX_ROWS (1 << 20)
+FS_API int fs_residual_noalloc(fs_solver* s, int which, double* out);
 /* sweeps (Jacobi) or CG iterations (MGPCG) the last fs_step / fs_stage_project actually ran */
 FS_API int fs_last_sweeps(const fs_solver* s);
 /* r.r after the last MGPCG solve (what the reference prints as rTr, Solver.cu:1272) */

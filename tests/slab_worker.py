@@ -18,12 +18,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def self_peer(fs, nx, ny, nz, steps, kw):
     """The middle slab of three, alone on this GPU, trading its boundary planes with itself over
-    RCCL (FS_TEST_SELF_PEER): no oracle for that, but the run with the transfers on the
+    RCCL (FS_FLAG_TEST_SELF_PEER): no oracle for that, but the run with the transfers on the
     communication stream (two events per exchange, Jacobi boundary launch on that stream) must
     equal the run with everything on the compute stream, bit for bit, and neither may hang."""
     import ctypes as C
     from fluidsolver_amd import slab as slabmod
-    os.environ["FS_TEST_SELF_PEER"] = "1"
     L = fs.load_library()
     slabmod._bind(L)
     rng = np.random.default_rng(11)
@@ -31,7 +30,7 @@ def self_peer(fs, nx, ny, nz, steps, kw):
     runs = []
     for streams in ("1", "0"):
         os.environ["FS_XCHG_STREAMS"] = streams
-        p = fs.default_params(nx, ny, 3 * nz, source_z=1.5 * nz, **kw)
+        p = fs.default_params(nx, ny, 3 * nz, source_z=1.5 * nz, flags=fs.FS_FLAG_TEST_SELF_PEER, **kw)
         s = slabmod.SlabSolver(p, 1, 3, transport="rccl")
         uid = (C.c_char * slabmod.FS_UNIQUE_ID_BYTES)()
         s._check(L.fs_comm_unique_id(uid))
@@ -52,6 +51,7 @@ def self_peer(fs, nx, ny, nz, steps, kw):
     # convergence mode on the same slab: the residual norm goes through ncclAllReduce
     del os.environ["FS_XCHG_STREAMS"]
     p = fs.default_params(nx, ny, 3 * nz, source_z=1.5 * nz, tolerance=1e-2, check_every=8, max_sweeps=64,
+                          flags=fs.FS_FLAG_TEST_SELF_PEER,
                           **{a: b for a, b in kw.items() if a != "jacobi_iters"})
     s = slabmod.SlabSolver(p, 1, 3, transport="rccl")
     uid = (C.c_char * slabmod.FS_UNIQUE_ID_BYTES)()

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(fs):
     for n in names:
         assert hasattr(L, n), "libfluidsolver.so does not export %s" % n
     from fluidsolver_amd import _capi
-    assert set(_capi.EXPORTED_SYMBOLS) <= set(names)
+    assert set(_capi.EXPORTED_SYMBOLS) == set(names)
 
 
 def test_default_params_mirror_reference_header(fs):

@@ -496,7 +496,8 @@ def test_headless_program_through_the_solver_class(fs, mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "fluidsolver_amd", "bin", "fs_headless")
     frames = 4
-    out = subprocess.run([exe, str(frames)] + (["shipped"] if mode == "shipped" else []), check=True,
+    # no argument = the class defaults = the reference's compiled-in configuration
+    out = subprocess.run([exe, str(frames)] + (["jacobi"] if mode == "jacobi" else []), check=True,
                          stdout=subprocess.PIPE, timeout=120, text=True).stdout
     assert out.count("frame: ") == frames and "frame: 0" in out and "frame: 3" in out
     m = re.search(r"sum\(rho\) ([-0-9.e+]+)\s+max\(rho\) ([-0-9.e+]+)\s+max\(uy\) ([-0-9.e+]+)", out)

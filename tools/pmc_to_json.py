@@ -57,6 +57,9 @@ for sub in sorted(os.listdir(src)):
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"dispatches": len(next(iter(d.values())))} for k, d in summary.items()}
 json.dump(out, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
+
 traffic = {}
 for cls, d in out.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
@@ -66,6 +69,10 @@ for cls, d in out.items():
                                   "read_factor": 2.0,
                                   "note": "x2 read correction calibrated for 16 B/lane streams" +
                                           ("" if cls in ("jacobi",) else "; uncalibrated for this access pattern"),
+                                  "SQ_INSTS_VALU": d.get("SQ_INSTS_VALU"),
                                   "source": tag}}
-json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+# the counter passes belong to the kernel sources they ran on: bench.py reports them only while
+# the sources in the tree still hash to this value
+json.dump({"source_hash": kernel_source_hash(), "tag": tag, "kernels": traffic},
+          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic.get("jacobi", {}), indent=1))

@@ -2,7 +2,7 @@
 """Rehearsal of one interior rank of the weak-scaling column on a single GPU.
 
 The middle slab (n x n x n) of a n x n x 3n column runs alone and trades its boundary planes with
-itself over RCCL (FS_TEST_SELF_PEER), once with the transfers ordered through the communication
+itself over RCCL (FS_FLAG_TEST_SELF_PEER), once with the transfers ordered through the communication
 stream (the default of the RCCL transport) and once with everything on the compute stream.  The
 transfers stay inside one GPU's memory, so this prices the slab overheads (boundary launches,
 wider halos, eager launches) and the stream ordering, not xGMI.
@@ -22,7 +22,6 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 80
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-    os.environ["FS_TEST_SELF_PEER"] = "1"
     import fluidsolver_amd as fs
     from fluidsolver_amd import slab as slabmod
     L = fs.load_library()
@@ -36,7 +35,7 @@ def main():
     print("single domain %d^3, %d sweeps: %.2f ms/step" % (n, sweeps, single))
     for streams, name in (("1", "two streams (RCCL default)"), ("0", "one stream")):
         os.environ["FS_XCHG_STREAMS"] = streams
-        p = fs.default_params(n, n, 3 * n, jacobi_iters=sweeps, source_z=1.5 * n)
+        p = fs.default_params(n, n, 3 * n, jacobi_iters=sweeps, source_z=1.5 * n, flags=fs.FS_FLAG_TEST_SELF_PEER)
         s = slabmod.SlabSolver(p, 1, 3, transport="rccl")
         uid = (C.c_char * slabmod.FS_UNIQUE_ID_BYTES)()
         s._check(L.fs_comm_unique_id(uid))
