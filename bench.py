@@ -222,7 +222,16 @@ def main():
         # torch.distributed is the control plane only (unique-id hand-out, barriers, max over
         # ranks); the halos travel inside the library over RCCL
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on stdout; the one JSON line must stay alone there
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     n = args.size
     nz_total = n * world if args.scaling == "weak" else n

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # every symbol include/fluidsolver.h declares
 EXPORTED_SYMBOLS = (
-    "fs_default_params", "fs_create", "fs_destroy", "fs_step", "fs_steps", "fs_sync", "fs_frame",
+    "fs_default_params", "fs_create", "fs_destroy", "fs_step", "fs_steps", "fs_sync", "fs_frame", "fs_step_graphs",
     "fs_stage_source", "fs_stage_force", "fs_stage_vorticity", "fs_stage_advect", "fs_stage_confine",
     "fs_stage_divergence",
     "fs_stage_jacobi", "fs_stage_project", "fs_stage_gradient", "fs_density_host",
@@ -73,7 +73,8 @@ class Layout(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libfluidsolver.so")
+    # FS_LIB_PATH: an alternative build of the same library (A/B timing of kernel variants)
+    return os.environ.get("FS_LIB_PATH") or os.path.join(_HERE, "lib", "libfluidsolver.so")
 
 
 _lib = None
@@ -96,7 +97,7 @@ def load_library():
     L.fs_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     for name in ("fs_destroy", "fs_step", "fs_sync", "fs_frame", "fs_stage_source", "fs_stage_force",
                  "fs_stage_advect", "fs_stage_divergence", "fs_stage_project", "fs_stage_gradient",
-                 "fs_stage_vorticity", "fs_stage_confine", "fs_last_sweeps"):
+                 "fs_stage_vorticity", "fs_stage_confine", "fs_last_sweeps", "fs_step_graphs"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = C.c_int
     L.fs_steps.argtypes = [vp, C.c_int]
@@ -287,6 +288,11 @@ class Solver:
         v = [C.c_int() for _ in range(4)]
         self._check(self._L.fs_jacobi_config(self._handle(), *[C.byref(x) for x in v]))
         return dict(zip(("variant", "tile_rows", "aligned_rows", "planes_per_chunk"), (x.value for x in v)))
+
+    @property
+    def step_graphs(self):
+        """captured step graphs held (-1: capture failed, eager launches)"""
+        return self._L.fs_step_graphs(self._handle())
 
     @property
     def comm_ranks(self):

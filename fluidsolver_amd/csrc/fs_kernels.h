@@ -37,6 +37,16 @@ struct FsSource {
 
 namespace fsk {
 
+// contiguous float ranges copied by one launch (either side may be pinned host memory)
+constexpr int kCopyBatchMax = 10;
+struct CopyBatch {
+    float* dst[kCopyBatchMax];
+    const float* src[kCopyBatchMax];
+    size_t n[kCopyBatchMax];
+    int count;
+};
+void copy_batch(hipStream_t st, const CopyBatch& b);
+
 #if defined(__HIPCC__)
 // x / 6.f, correctly rounded for every binary32 x (what the true division of the reference yields,
 // Solver.cu:160, 441), as RN32(RN64(x * RN64(1/6))): three instructions instead of the ten of the

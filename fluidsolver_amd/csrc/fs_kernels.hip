@@ -12,6 +12,7 @@
 //   pressure gradient :446-483, residual :442.
 #include "fs_kernels.h"
 
+#include <cstdint>
 #include <mutex>
 
 #pragma clang fp contract(off)
@@ -93,6 +94,25 @@ __global__ void k_force4(float* __restrict__ uy, const float* __restrict__ T, fl
     u.z += (a.z * (1.0f - 0.5f) + c.z * 0.5f - T_env) * dt;
     u.w += (a.w * (1.0f - 0.5f) + c.w * 0.5f - T_env) * dt;
     *dst = u;
+}
+
+// Up to kCopyBatchMax contiguous float ranges copied by one launch (blockIdx.y = range).  Used to
+// pack halo planes into, and unpack them from, pinned host memory that the GPU addresses directly.
+__global__ void __launch_bounds__(256) k_copy_batch(fsk::CopyBatch b)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int r = blockIdx.y;
+    const size_t n = b.n[r];
+    float* __restrict__ dst = b.dst[r];
+    const float* __restrict__ src = b.src[r];
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+        const size_t n4 = n / 4;
+        for (size_t i = t; i < n4; i += stride) ((f4*)dst)[i] = ((const f4*)src)[i];
+        for (size_t i = 4 * n4 + t; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (size_t i = t; i < n; i += stride) dst[i] = src[i];
+    }
 }
 
 // ---------------------------------------------------------------- projection
@@ -250,6 +270,16 @@ const dim3 kTile(64, 4, 1);
 }  // namespace
 
 namespace fsk {
+
+void copy_batch(hipStream_t st, const CopyBatch& b)
+{
+    if (b.count <= 0) return;
+    size_t nmax = 0;
+    for (int r = 0; r < b.count; ++r) nmax = b.n[r] > nmax ? b.n[r] : nmax;
+    if (nmax == 0) return;
+    const unsigned blocks = (unsigned)((nmax / 4 + 255) / 256);
+    hipLaunchKernelGGL(k_copy_batch, dim3(blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks), b.count), dim3(256), 0, st, b);
+}
 
 void fill_interior(hipStream_t st, const FsGrid& g, float* f, float value)
 {

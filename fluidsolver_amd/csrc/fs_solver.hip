@@ -178,14 +178,28 @@ struct fs_solver {
     struct XMark { hipEvent_t ev; const char* what; int xchg; char queue; };
     int dbg_xchg = 0;
     int xchg_seq = 0;                 // exchanges begun so far
+    // With several processes on one GPU (the host-staged test rig) a compute queue parked in
+    // hipStreamWaitEvent(ev_done) was seen to keep the communication queue's next dispatch - the
+    // very operation it waits for - from starting.  host_wait = the host waits instead (default of
+    // the host-staged transport; FS_XCHG_HOST_WAIT=0 / 1 forces either on either transport).
+    bool host_wait = false;
     int xchg_timeout_ms = 60000;      // FS_XCHG_TIMEOUT_MS: limit of a host-side wait inside an exchange
     std::vector<XMark> marks;         // oldest first; completed marks are recycled from the front
     // captured steps: a step only launches kernels whose arguments are the field pointers and
     // constants, so a graph captured for one assignment of the 13 buffers to their roles can be
     // replayed whenever the buffers are in that assignment again (the ping-pong swaps give the
     // assignment a period of two steps)
-    struct StepGraph { FsFields before, after; bool prev_held; hipGraphExec_t exec; };
+    // (a slab's graph also depends on which ghost planes were valid when it was captured: the
+    // exchanges it contains are the ones that state asked for)
+    struct HostState {
+        FsFields f;
+        bool prev_held, vel_ghost_ok, scal_ghost_ok, div_fresh;
+        int p_ghost;
+    };
+    struct StepGraph { HostState before, after; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
+    int eager_steps_left = 0;         // slabs: the first steps run eagerly (RCCL sets up its connections)
+    bool graph_failed = false;        // a capture failed once: this solver launches eagerly from then on
     // stage timing with HIP events on the solver's own stream (fs_profile_*)
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
@@ -276,6 +290,16 @@ Seg make_seg(const fs_solver* s, float* base, int n, bool face)
     return g;
 }
 
+// FS_DEBUG_XCHG=2: a line on stderr before every call of the exchange code that could block the
+// host, so the last line of a stuck rank names the call it sits in
+#define FS_TRACE(s, what)                                                                      \
+    do {                                                                                       \
+        if ((s)->dbg_xchg >= 2) {                                                              \
+            fprintf(stderr, "[fluidsolver rank %d] exchange %d: %s\n", (s)->rank, (s)->xchg_seq, what); \
+            fflush(stderr);                                                                    \
+        }                                                                                      \
+    } while (0)
+
 // FS_DEBUG_XCHG: label the point both queues have reached.  `what` must be a string literal.
 void xmark(fs_solver* s, hipStream_t q, const char* what)
 {
@@ -333,6 +357,7 @@ void xchg_report(fs_solver* s, const char* where, double waited_s)
 // both queues hold instead of a silent hang.
 int bounded_sync(fs_solver* s, hipStream_t q, const char* where)
 {
+    FS_TRACE(s, where);
     if (s->xchg_timeout_ms <= 0) {
         FS_HIP(hipStreamSynchronize(q));
         return FS_OK;
@@ -365,18 +390,26 @@ int bounded_sync(fs_solver* s, hipStream_t q, const char* where)
 int exchange_wait(fs_solver* s)
 {
     if (!s->halo_pending) return FS_OK;
+    if (s->host_wait) {
+        // the host waits for the received planes instead of the compute queue, so no queue ever
+        // parks in a wait on another queue (default of the host-staged transport, whose host is in
+        // the middle of every exchange anyway; see FS_XCHG_HOST_WAIT)
+        int rc = bounded_sync(s, s->cs, "host-side wait for the received planes");
+        if (rc) return rc;
+        s->halo_pending = false;
+        return FS_OK;
+    }
+    FS_TRACE(s, "hipStreamWaitEvent(compute, ev_done)");
     FS_HIP(hipStreamWaitEvent(s->st, s->ev_done, 0));
     s->halo_pending = false;
     xmark(s, s->st, "wait for the received planes (ev_done)");
     return FS_OK;
 }
 
-// RCCL transport: the transfer runs on the communication stream (highest priority), ordered after
-// everything enqueued on the compute stream so far, and overlaps with what the caller enqueues on
-// the compute stream next.  Host-staged transport: by default everything stays on the compute
-// stream and the call returns with the planes received (ranks that share one GPU and each wait
-// across two queues were seen to stall one another).
-// FS_XCHG_STREAMS=1 / 0 forces the two-stream / one-stream ordering on either transport.
+// The transfer runs on the communication stream, ordered after everything enqueued on the compute
+// stream so far (ev_ready), and overlaps with what the caller enqueues on the compute stream next;
+// exchange_wait() orders the compute stream after it (ev_done).  Both transports share this
+// ordering.  FS_XCHG_STREAMS=0 puts everything on the compute stream instead (no overlap).
 int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
 {
     if (s->world == 1 || nseg == 0) return FS_OK;
@@ -385,14 +418,16 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
         if (rc) return rc;
     }
     const bool lo = !s->g.wall_lo, hi = !s->g.wall_hi;
-    const bool two_streams = s->xchg_streams >= 0 ? s->xchg_streams != 0 : s->comm != nullptr;
+    const bool two_streams = s->xchg_streams != 0;
     hipStream_t q = s->st;
     ++s->xchg_seq;
     if (two_streams) {
         // the communication stream waits for the producers on the compute stream ...
         q = s->cs;
+        FS_TRACE(s, "hipEventRecord(ev_ready, compute)");
         FS_HIP(hipEventRecord(s->ev_ready, s->st));
         xmark(s, s->st, "producers of the planes to send (ev_ready)");
+        FS_TRACE(s, "hipStreamWaitEvent(communication, ev_ready)");
         FS_HIP(hipStreamWaitEvent(q, s->ev_ready, 0));
         xmark(s, q, "wait for the producers (ev_ready)");
     }
@@ -422,39 +457,57 @@ int exchange_begin(fs_solver* s, const Seg* segs, int nseg)
             for (char*& b : s->h_stage) {
                 if (b) (void)hipHostFree(b);
                 b = nullptr;
-                FS_HIP(hipHostMalloc((void**)&b, bytes));
+                // coherent (fine-grained) host memory: the GPU reads what the callback just wrote
+                // and the host sees the packed planes once the kernel has completed
+                FS_HIP(hipHostMalloc((void**)&b, bytes, hipHostMallocCoherent));
             }
             s->h_stage_cap = bytes;
         }
+        // The planes are packed into / unpacked from the pinned buffers by a kernel of this library
+        // that addresses the host memory directly, one launch per direction of the exchange.  (The
+        // runtime's asynchronous copies were what stalled when this transport ran on the
+        // communication stream with several ranks on one GPU: the host-to-device copies of the
+        // received planes stayed at the head of that stream's queue, all of their predecessors
+        // complete, with the copy engines enabled or disabled.)
+        if (nseg > fsk::kCopyBatchMax / 2) return fail(FS_ERR_INVALID, "exchange of %d segments", nseg);
+        fsk::CopyBatch out{}, in{};
         size_t off = 0;
         for (int i = 0; i < nseg; ++i) {
             const size_t nb = segs[i].n * sizeof(float);
-            if (lo) FS_HIP(hipMemcpyAsync(s->h_stage[0] + off, segs[i].send_lo, nb, hipMemcpyDeviceToHost, q));
-            if (hi) FS_HIP(hipMemcpyAsync(s->h_stage[2] + off, segs[i].send_hi, nb, hipMemcpyDeviceToHost, q));
+            if (lo) {
+                out.dst[out.count] = (float*)(s->h_stage[0] + off); out.src[out.count] = segs[i].send_lo; out.n[out.count++] = segs[i].n;
+                in.dst[in.count] = segs[i].recv_lo; in.src[in.count] = (const float*)(s->h_stage[1] + off); in.n[in.count++] = segs[i].n;
+            }
+            if (hi) {
+                out.dst[out.count] = (float*)(s->h_stage[2] + off); out.src[out.count] = segs[i].send_hi; out.n[out.count++] = segs[i].n;
+                in.dst[in.count] = segs[i].recv_hi; in.src[in.count] = (const float*)(s->h_stage[3] + off); in.n[in.count++] = segs[i].n;
+            }
             off += nb;
         }
+        FS_TRACE(s, "launch pack kernel");
+        fsk::copy_batch(q, out);
+        FS_HIP(hipGetLastError());
         xmark(s, q, "copies of the planes to send into pinned memory");
         {
             int rc = bounded_sync(s, q, "halo exchange, device-to-host copies");
             if (rc) return rc;
         }
+        FS_TRACE(s, "callback");
         int rc = s->xfn(s->xctx, FS_XCHG_HALO, lo ? s->h_stage[0] : nullptr, lo ? s->h_stage[1] : nullptr,
                         hi ? s->h_stage[2] : nullptr, hi ? s->h_stage[3] : nullptr, bytes);
         if (rc) return fail(FS_ERR_COMM, "rank %d: the exchange callback returned %d", s->rank, rc);
-        off = 0;
-        for (int i = 0; i < nseg; ++i) {
-            const size_t nb = segs[i].n * sizeof(float);
-            if (lo) FS_HIP(hipMemcpyAsync(segs[i].recv_lo, s->h_stage[1] + off, nb, hipMemcpyHostToDevice, q));
-            if (hi) FS_HIP(hipMemcpyAsync(segs[i].recv_hi, s->h_stage[3] + off, nb, hipMemcpyHostToDevice, q));
-            off += nb;
-        }
+        FS_TRACE(s, "launch unpack kernel");
+        fsk::copy_batch(q, in);
+        FS_HIP(hipGetLastError());
         xmark(s, q, "copies of the received planes into the ghost planes");
     }
     if (two_streams) {
         // ... and the consumers on the compute stream wait for the halos in exchange_wait()
+        FS_TRACE(s, "hipEventRecord(ev_done, communication)");
         FS_HIP(hipEventRecord(s->ev_done, q));
         s->halo_pending = true;
     }
+    FS_TRACE(s, "exchange_begin returns");
     return FS_OK;
 }
 
@@ -569,11 +622,13 @@ int run_jacobi(fs_solver* s, int sweeps)
                 const int ilo = g.wall_lo ? g.z0 : g.z0 + T, ihi = g.wall_hi ? z1 : z1 - T;
                 // (first on the compute stream: run beside the interior launch, which fills every CU,
                 // they took 180 us instead of 25 and delayed the transfer that waits for them)
+                FS_TRACE(s, "launch Jacobi boundary planes");
                 fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, g.z0, ilo, ihi, z1);
                 xmark(s, s->st, "Jacobi pass, boundary planes");
                 Seg seg = make_seg(s, s->f.np, T, false);
                 rc = exchange_begin(s, &seg, 1);
                 if (rc) return rc;
+                FS_TRACE(s, "launch Jacobi interior planes");
                 fsk::jacobi_pass(s->st, g, s->f.p, s->f.np, s->f.div, t, zin_lo, zin_hi, ilo, ihi);
                 xmark(s, s->st, "Jacobi pass, interior planes");
                 std::swap(s->f.p, s->f.np);
@@ -731,8 +786,8 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                                         "(mg_level %d)", m, p->mg_level);
         if (p->tolerance > 0.f) return fail(FS_ERR_INVALID, "fs_create: convergence mode is for the Jacobi solver");
     }
-    if ((p->flags & FS_FLAG_TEST_SELF_PEER) && !(world > 1 && unique_id))
-        return fail(FS_ERR_INVALID, "fs_create: FS_FLAG_TEST_SELF_PEER is a test hook of RCCL slabs");
+    if ((p->flags & FS_FLAG_TEST_SELF_PEER) && world < 2)
+        return fail(FS_ERR_INVALID, "fs_create: FS_FLAG_TEST_SELF_PEER is a test hook of z-slabs");
     if (world > 1 && (p->flags & FS_FLAG_VORT_CONFINE))
         return fail(FS_ERR_INVALID, "fs_create_slab: FS_FLAG_VORT_CONFINE is single-GPU only (its gathers "
                                     "mix z planes through mismatched strides)");
@@ -873,12 +928,14 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         if (world > 1) {
             // the halo transfers are short and sit on the critical path of the next pass: give
             // their stream the highest priority so they are not queued behind the interior kernels
-            // (RCCL transport only: host-staged ranks may share one GPU, where several processes'
-            // high-priority queues waiting on their own normal-priority queues starve each other)
+            // (RCCL transport only: host-staged ranks may share one GPU, and the transfers there wait
+            // for the host in the middle)
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
             if (const char* e = getenv("FS_XCHG_STREAMS")) s->xchg_streams = atoi(e) != 0;
             if (const char* e = getenv("FS_DEBUG_XCHG")) s->dbg_xchg = atoi(e);
+            s->host_wait = unique_id == nullptr;
+            if (const char* e = getenv("FS_XCHG_HOST_WAIT")) s->host_wait = atoi(e) != 0;
             if (const char* e = getenv("FS_XCHG_TIMEOUT_MS")) s->xchg_timeout_ms = atoi(e);
             if (hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, unique_id ? prio_hi : prio_lo) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
@@ -911,6 +968,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         // zero state: every ghost plane already equals its neighbour's owned plane
         s->vel_ghost_ok = s->scal_ghost_ok = true;
         s->p_ghost = g.ghost;
+        s->eager_steps_left = world > 1 ? 2 : 0;
         if (hipStreamSynchronize(s->st) != hipSuccess || hipGetLastError() != hipSuccess) {
             rc = fail(FS_ERR_HIP, "fs_create: initialisation kernels failed");
             break;
@@ -1269,29 +1327,60 @@ int fs_stage_gradient(fs_solver* s)
 static int step_eager(fs_solver* s)
 {
     int rc;
+    FS_TRACE(s, "step: source, force");
     if ((rc = fs_stage_source(s))) return rc;
     if ((rc = fs_stage_force(s))) return rc;
     if ((rc = fs_stage_vorticity(s))) return rc;
+    FS_TRACE(s, "step: advect");
     if ((rc = stage_advect(s, true))) return rc;
     if ((rc = fs_stage_confine(s))) return rc;
+    FS_TRACE(s, "step: project");
     if ((rc = fs_stage_project(s))) return rc;
-    return fs_stage_gradient(s);
+    FS_TRACE(s, "step: gradient");
+    rc = fs_stage_gradient(s);
+    FS_TRACE(s, "step: done");
+    return rc;
 }
 
-static bool same_fields(const FsFields& a, const FsFields& b) { return std::memcmp(&a, &b, sizeof(FsFields)) == 0; }
+static fs_solver::HostState host_state(const fs_solver* s)
+{
+    return {s->f, s->prev_held, s->vel_ghost_ok, s->scal_ghost_ok, s->div_fresh, s->p_ghost};
+}
 
-// One step as a graph replay: single slab, fixed sweep count, no stage timing.
+static void set_host_state(fs_solver* s, const fs_solver::HostState& h)
+{
+    s->f = h.f;
+    s->prev_held = h.prev_held;
+    s->vel_ghost_ok = h.vel_ghost_ok;
+    s->scal_ghost_ok = h.scal_ghost_ok;
+    s->div_fresh = h.div_fresh;
+    s->p_ghost = h.p_ghost;
+}
+
+// what decides which launches and exchanges a step makes: the buffer assignment and, on a slab,
+// the validity of the ghost planes
+static bool same_launches(const fs_solver* s, const fs_solver::HostState& a, const fs_solver::HostState& b)
+{
+    if (std::memcmp(&a.f, &b.f, sizeof(FsFields)) != 0) return false;
+    if (s->world == 1) return true;
+    return a.vel_ghost_ok == b.vel_ghost_ok && a.scal_ghost_ok == b.scal_ghost_ok && a.p_ghost == b.p_ghost &&
+           a.div_fresh == b.div_fresh;
+}
+
+// One step as a graph replay: fixed sweep count, no stage timing; one GPU (a slab on the RCCL
+// transport only with FS_SLAB_GRAPH=1, see fs_step: its sends and receives would be captured on
+// the communication stream, which the event pair of each exchange forks from and joins back into
+// the compute stream).
 static int step_graph(fs_solver* s)
 {
     FS_HIP(hipSetDevice(s->device));
+    const fs_solver::HostState now = host_state(s);
     for (const fs_solver::StepGraph& g : s->graphs) {
-        if (!same_fields(g.before, s->f)) continue;
+        if (!same_launches(s, g.before, now)) continue;
         FS_HIP(hipGraphLaunch(g.exec, s->st));
         // host-side state as the eager stages leave it
-        s->f = g.after;
-        s->prev_held = g.prev_held;
+        set_host_state(s, g.after);
         s->last_sweeps = s->prm.jacobi_iters;
-        s->div_fresh = false;          // the gradient changed the velocity last
         return FS_OK;
     }
     if (s->graphs.size() >= 8) {   // an unusual sequence of stage calls and uploads: start over
@@ -1299,21 +1388,32 @@ static int step_graph(fs_solver* s)
         s->graphs.clear();
     }
     fs_solver::StepGraph g{};
-    g.before = s->f;
+    g.before = now;
     FS_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
     int rc = step_eager(s);
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(s->st, &graph);
-    if (rc) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
+    if (rc == FS_OK && e == hipSuccess) {
+        e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) g.exec = nullptr;
     }
-    if (e != hipSuccess) return fail(FS_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) return fail(FS_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-    g.after = s->f;
-    g.prev_held = s->prev_held;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc != FS_OK || e != hipSuccess) {
+        // nothing ran while capturing: put the host-side state back
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        (void)hipGetLastError();
+        set_host_state(s, now);
+        s->halo_pending = false;
+        if (s->world == 1) {
+            if (rc) return rc;
+            return fail(FS_ERR_HIP, "capture of a step failed: %s", hipGetErrorString(e));
+        }
+        // a slab falls back to eager launches for good (a communication library that cannot be
+        // captured on this machine must not cost the run)
+        s->graph_failed = true;
+        return step_eager(s);
+    }
+    g.after = host_state(s);
     s->graphs.push_back(g);
     FS_HIP(hipGraphLaunch(g.exec, s->st));
     return FS_OK;
@@ -1323,12 +1423,34 @@ int fs_step(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     // (the CG loop reads its scalars on the host, so an MGPCG step cannot be captured)
-    const bool graph = s->world == 1 && s->prm.tolerance <= 0.f && !s->profiling &&
-                       s->prm.pressure_solver == FS_PRESSURE_JACOBI && !(s->prm.flags & FS_FLAG_NO_GRAPH);
+    bool graph = s->prm.tolerance <= 0.f && !s->profiling && s->prm.pressure_solver == FS_PRESSURE_JACOBI &&
+                 !(s->prm.flags & FS_FLAG_NO_GRAPH) && !s->graph_failed && !s->dbg_xchg && !s->host_wait;
+    if (s->world > 1) {
+        // Slabs launch eagerly.  Capturing a slab step (RCCL transport only, after a few eager
+        // steps in which RCCL sets up its connections) is wired up behind FS_SLAB_GRAPH=1 but stays
+        // off: with RCCL 2.26.6 the captured ncclSend/ncclRecv group of a rank that is its own
+        // neighbour (the only form a one-GPU machine can run) ended in a segmentation fault inside
+        // the library, and the capture has never run between two devices.
+        static const bool slab_graph = [] {
+            const char* e = getenv("FS_SLAB_GRAPH");
+            return e && atoi(e) != 0;
+        }();
+        graph = graph && slab_graph && s->comm != nullptr;
+        if (graph && s->eager_steps_left > 0) {
+            --s->eager_steps_left;
+            graph = false;
+        }
+    }
     int rc = graph ? step_graph(s) : step_eager(s);
     if (rc) return rc;
     s->frame++;
     return FS_OK;
+}
+
+int fs_step_graphs(const fs_solver* s)
+{
+    if (!s) return -2;
+    return s->graph_failed ? -1 : (int)s->graphs.size();
 }
 
 int fs_steps(fs_solver* s, int n)

@@ -63,10 +63,11 @@ enum {
        arithmetic arrays of (nx+1)(ny+1)(nz+1) zero-initialised floats, so every read is defined.
        Single GPU only. */
     FS_FLAG_VORT_CONFINE = 1 << 2,
-    /* Test hook, RCCL slabs only: the slab keeps its place in the decomposition but its RCCL
-       communicator holds this rank alone and both neighbours are the rank itself, so one GPU can
-       drive ncclSend/ncclRecv and the stream ordering.  The results are NOT those of the
-       decomposed grid; never set it in a real multi-rank run. */
+    /* Test hook of z-slabs: the slab keeps its place in the decomposition but both neighbours are
+       the rank itself (RCCL transport: its communicator holds this rank alone; host-staged
+       transport: the exchange function is expected to hand send_hi back as recv_lo and send_lo as
+       recv_hi), so one process on one GPU can drive the transfers and the stream ordering.  The
+       results are NOT those of the decomposed grid; never set it in a real multi-rank run. */
     FS_FLAG_TEST_SELF_PEER = 1 << 3
 };
 
@@ -164,6 +165,11 @@ FS_API int fs_step(fs_solver* s);
 FS_API int fs_steps(fs_solver* s, int n);
 FS_API int fs_sync(fs_solver* s);
 FS_API int fs_frame(const fs_solver* s);          /* Solver.h:76 current_frame */
+/* fs_step replays a captured hipGraph per assignment of the buffers where it can (one GPU, fixed
+   sweep count, no stage timing; z-slabs launch eagerly).
+   Returns the number of step graphs this solver holds, -1 if a capture failed and the solver went
+   back to eager launches (no counterpart in the reference, which launches eagerly). */
+FS_API int fs_step_graphs(const fs_solver* s);
 
 /* -- individual stages, in the order fs_step runs them.  The reference exposes
       Advect() and Project() as public members (Solver.h:24,26); the others are its

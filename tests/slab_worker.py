@@ -19,8 +19,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def self_peer(fs, nx, ny, nz, steps, kw):
     """The middle slab of three, alone on this GPU, trading its boundary planes with itself over
     RCCL (FS_FLAG_TEST_SELF_PEER): no oracle for that, but the run with the transfers on the
-    communication stream (two events per exchange, Jacobi boundary launch on that stream) must
-    equal the run with everything on the compute stream, bit for bit, and neither may hang."""
+    communication stream (two events per exchange) must equal the run with everything on the
+    compute stream, bit for bit, and neither may hang."""
     import ctypes as C
     from fluidsolver_amd import slab as slabmod
     L = fs.load_library()
@@ -28,9 +28,9 @@ def self_peer(fs, nx, ny, nz, steps, kw):
     rng = np.random.default_rng(11)
     init = None
     runs = []
-    for streams in ("1", "0"):
+    for streams, extra_flags in (("1", 0), ("0", 0)):
         os.environ["FS_XCHG_STREAMS"] = streams
-        p = fs.default_params(nx, ny, 3 * nz, source_z=1.5 * nz, flags=fs.FS_FLAG_TEST_SELF_PEER, **kw)
+        p = fs.default_params(nx, ny, 3 * nz, source_z=1.5 * nz, flags=fs.FS_FLAG_TEST_SELF_PEER | extra_flags, **kw)
         s = slabmod.SlabSolver(p, 1, 3, transport="rccl")
         uid = (C.c_char * slabmod.FS_UNIQUE_ID_BYTES)()
         s._check(L.fs_comm_unique_id(uid))
@@ -69,6 +69,46 @@ def self_peer(fs, nx, ny, nz, steps, kw):
     sys.exit(0 if ok and moved else 1)
 
 
+def self_peer_host(fs, nx, ny, nz, steps, kw):
+    """The same middle slab on the host-staged transport, still one process: the exchange function
+    hands the planes sent upwards back as the planes received from below and vice versa.  The
+    two-stream ordering must equal the one-stream ordering bit for bit."""
+    import ctypes as C
+    from fluidsolver_amd import slab as slabmod
+    L = fs.load_library()
+    slabmod._bind(L)
+
+    def fn(ctx, op, send_lo, recv_lo, send_hi, recv_hi, nbytes):
+        if op == slabmod.FS_XCHG_HALO:
+            C.memmove(recv_lo, send_hi, nbytes)
+            C.memmove(recv_hi, send_lo, nbytes)
+        return 0
+
+    cb = slabmod._EXCHANGE_FN(fn)
+    rng = np.random.default_rng(12)
+    init, runs = None, []
+    for streams in ("1", "0"):
+        os.environ["FS_XCHG_STREAMS"] = streams
+        p = fs.default_params(nx, ny, 3 * nz, source_z=1.5 * nz, flags=fs.FS_FLAG_TEST_SELF_PEER, **kw)
+        s = slabmod.SlabSolver(p, 1, 3, transport="host")
+        h = C.c_void_p()
+        s._check(L.fs_create_slab(C.byref(p), 1, 3, None, cb, None, C.byref(h)))
+        s._h = h
+        if init is None:
+            init = {f: (rng.standard_normal(s.local_shape(f)) * (0.8 if f < 3 else 0.3)).astype(np.float32)
+                    for f in range(5)}
+        for f, a in init.items():
+            s.upload(f, a)
+        s.step(steps)
+        s.sync()
+        runs.append([s.field(f) for f in range(6)])
+        s.close()
+    ok = all(np.array_equal(a, b) for a, b in zip(*runs)) and all(np.isfinite(a).all() for a in runs[0])
+    moved = not np.array_equal(runs[0][0], init[0])
+    print("SLAB_OK" if ok and moved else "SLAB_FAIL")
+    sys.exit(0 if ok and moved else 1)
+
+
 def main():
     # a stuck worker prints the Python stacks of its threads and exits instead of waiting for the
     # parent's time limit
@@ -92,6 +132,8 @@ def main():
     kw = dict(jacobi_iters=k, source_y=min(10.0, ny / 3.0), source_radius=min(7.0, min(nx, ny, nz) / 4.0))
     if mode == "selfpeer":
         return self_peer(fs, nx, ny, nz, steps, kw)
+    if mode == "selfpeer_host":
+        return self_peer_host(fs, nx, ny, nz, steps, kw)
     if "naive" in extra:
         kw["flags"] = fs.FS_FLAG_JACOBI_NAIVE
     if "converge" in extra:
@@ -156,6 +198,13 @@ def main():
                 ok = False
         if not ok:
             break
+    if steps:
+        # asynchronous read-back on a slab: the pinned buffer holds the LOCAL planes only
+        s.field_begin(fs.FS_UZ)
+        got = s.field_end(fs.FS_UZ)
+        if got.shape != s.local_shape(fs.FS_UZ) or not np.array_equal(got, s.field(fs.FS_UZ)):
+            print("rank %d: asynchronous read-back of uz differs from the blocking one" % rank)
+            ok = False
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     s.close()

@@ -81,6 +81,31 @@ def test_renderer_compiles_against_our_solver_header():
         assert r.returncode == 0, r.stdout[-2000:]
 
 
+@pytest.mark.skipif(shutil.which("cmake") is None, reason="cmake absent")
+def test_linux_cmake_build_of_the_solver_consumers(tmp_path):
+    """integration/CMakeLists.txt (the Linux stand-in for the reference's top-level CMakeLists.txt:
+    CuSolver as an imported shared library instead of add_subdirectory(CuSolver)) configures and
+    builds the solver-only consumers; with a reference checkout it goes on to the Renderer, which
+    stops at find_package(glfw3) in this image (no GLFW development files)."""
+    if not os.path.exists(os.path.join(ROOT, "fluidsolver_amd", "lib", "libCuSolver.so")):
+        pytest.skip("library not built")
+    b = str(tmp_path / "b")
+    r = subprocess.run(["cmake", "-S", os.path.join(ROOT, "integration"), "-B", b, "-DFLUIDSOLVER_AMD=" + ROOT],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    r = subprocess.run(["cmake", "--build", b, "--target", "fs_headless"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    out = subprocess.run(["ldd", os.path.join(b, "Bin", "fs_headless")], stdout=subprocess.PIPE, text=True).stdout
+    assert "libCuSolver.so" in out and "libfluidsolver.so" in out and "not found" not in out
+    if os.path.isdir(REF):
+        r = subprocess.run(["cmake", "-S", os.path.join(ROOT, "integration"), "-B", str(tmp_path / "r"),
+                            "-DFLUIDSOLVER_AMD=" + ROOT, "-DREFERENCE_DIR=" + REF],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        # either GLFW is installed and the Renderer configures, or the only complaint is GLFW
+        assert r.returncode == 0 or "glfw3" in r.stdout, r.stdout[-2000:]
+
+
 def test_headless_host_program_links_the_shim():
     exe = os.path.join(ROOT, "fluidsolver_amd", "bin", "fs_headless")
     if not os.path.exists(exe):

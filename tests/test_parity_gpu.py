@@ -263,6 +263,8 @@ def test_graph_replay_matches_eager_launches(fs, oracle, k):
     g.step(2); e.step(2); o.step(); o.step()
     assert_all_equal(g, o, what="graph k=%d final" % k)
     assert_all_equal(e, o, what="eager k=%d final" % k)
+    # the graph path was really taken: at least one graph per buffer assignment met, none eagerly
+    assert 1 <= g.step_graphs <= 8 and e.step_graphs == 0
     g.close(); e.close(); o.close()
 
 

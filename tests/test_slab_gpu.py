@@ -2,8 +2,8 @@
 
 The ranks share the one GPU of the test box and move their halos through host buffers and
 gloo (`transport="host"`): everything except the RCCL calls themselves is the production
-path (slab kernels, ghost-plane bookkeeping, fused Jacobi passes with wide halos, residual
-all-reduce)."""
+path (slab kernels, ghost-plane bookkeeping, fused Jacobi passes with wide halos, transfers on
+the communication stream ordered by two events per exchange, residual all-reduce)."""
 import os
 import subprocess
 import sys
@@ -19,10 +19,28 @@ def run_ranks(world, args, port, env_extra=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "slab_worker.py")] + [str(a) for a in args]
-    env = dict(os.environ, OMP_NUM_THREADS="4", **(env_extra or {}))
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       timeout=280, text=True)
-    assert r.returncode == 0 and "SLAB_OK" in r.stdout, r.stdout[-3000:]
+    # a stuck worker dumps its Python stacks and exits after 100 s, a stalled exchange reports the
+    # queue states after 40 s: either ends the run well before the launcher's own limit
+    env = dict({"FS_WORKER_DUMP_AFTER": "100", "FS_XCHG_TIMEOUT_MS": "40000"}, **os.environ)
+    env.update(OMP_NUM_THREADS="4", **(env_extra or {}))
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=160, text=True)
+    except subprocess.TimeoutExpired as e:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "slab_fail_%d.log" % port), "w") as f:
+            f.write((e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""))
+        raise
+    if r.returncode != 0 or "SLAB_OK" not in r.stdout:
+        # keep the whole output of a failed run (the library's stall report precedes the
+        # launcher's traceback) where a GPU-box run returns it
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "slab_fail_%d.log" % port), "w") as f:
+            f.write(r.stdout)
+        lines = [ln for ln in r.stdout.splitlines() if "[fluidsolver" in ln or "differs" in ln or "SLAB_" in ln]
+        raise AssertionError("\n".join(lines[-40:]) + "\n...\n" + r.stdout[-1500:])
 
 
 @pytest.mark.parametrize("world,dims,steps,k,extra", [
@@ -44,6 +62,41 @@ def test_slab_tall_tiles_multi_tile():
     run_ranks(2, ["host", 72, 68, 24, 3, 7], 29621, {"FS_JACOBI_CFG": "0"})
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("world,k", [(2, 7), (3, 8)])
+def test_slab_every_tile_variant(cfg, world, k):
+    """Every tile variant of the blocked Jacobi kernel (64 / 32 rows, plain / 64-byte aligned output
+    rows) on slabs, several tiles per plane in x and y (132 x 70), passes of 4 and 3 sweeps; the
+    3-rank run has an interior rank whose boundary launch covers two plane ranges.  On a slab the
+    variant is otherwise whatever the timing at creation picks, so it is pinned here."""
+    run_ranks(world, ["host", 132, 70, 40, 2, k, "random"], 29670 + 4 * world + cfg,
+              {"FS_JACOBI_CFG": str(cfg), "FS_JACOBI_TUNE": "0"})
+
+
+@pytest.mark.parametrize("cfg", [0, 3])
+def test_slab_boundary_launch_with_several_chunks_per_range(cfg):
+    """FS_JACOBI_LZ=2: the 4 boundary planes next to each neighbour are cut into two z chunks, so
+    the interior rank's boundary launch has two chunks in each of its two output ranges."""
+    run_ranks(3, ["host", 68, 40, 36, 2, 8, "random"], 29690 + cfg,
+              {"FS_JACOBI_CFG": str(cfg), "FS_JACOBI_LZ": "2", "FS_JACOBI_TUNE": "0"})
+
+
+def test_slab_one_stream_ordering_fallback():
+    """FS_XCHG_STREAMS=0: the fall-back ordering with every transfer on the compute stream (no
+    overlap) gives the same fields."""
+    run_ranks(3, ["host", 20, 16, 48, 3, 8, "random"], 29698, {"FS_XCHG_STREAMS": "0"})
+
+
+def test_slab_two_stream_ordering_with_tracing():
+    """Four ranks on one GPU with the transfers on the communication stream (the default ordering
+    of both transports; on this transport the host, not the compute stream, waits for the received
+    planes) and FS_DEBUG_XCHG tracing on: every wait inside an exchange is bounded and a stall
+    would end the run with a report of the operation at the head of each queue."""
+    run_ranks(4, ["host", 16, 16, 40, 4, 12], 29699,
+              {"FS_XCHG_STREAMS": "1", "FS_DEBUG_XCHG": "1", "FS_XCHG_TIMEOUT_MS": "30000",
+               "FS_WORKER_DUMP_AFTER": "120"})
+
+
 def test_slab_convergence_mode():
     """tolerance > 0: the residual norm is all-reduced over the ranks every check_every sweeps."""
     run_ranks(2, ["host", 24, 24, 24, 3, 0, "converge"], 29631)
@@ -58,7 +111,14 @@ def test_slab_reports_a_back_trace_beyond_the_ghost_planes():
 def test_rccl_send_recv_and_stream_ordering_with_itself_as_neighbour():
     """RCCL on one GPU: the middle slab of three exchanges with itself (see slab_worker.self_peer);
     two-stream ordering against one-stream ordering, 12 steps of 7 exchanges each."""
-    run_ranks(1, ["selfpeer", 64, 48, 24, 12, 20], 29661)
+    run_ranks(1, ["selfpeer", 64, 48, 24, 12, 20], 29661, {"FS_DEBUG_XCHG": "0"})   # tracing would keep the steps eager
+
+
+def test_host_transport_stream_ordering_with_itself_as_neighbour():
+    """The host-staged transport in ONE process (the exchange function loops the planes back) with
+    the compute stream itself waiting for the received planes (FS_XCHG_HOST_WAIT=0, the ordering of
+    the RCCL transport): two-stream ordering against one-stream ordering, 12 steps."""
+    run_ranks(1, ["selfpeer_host", 64, 48, 24, 12, 20], 29662, {"FS_XCHG_HOST_WAIT": "0"})
 
 
 def test_single_rank_rccl_communicator():

@@ -15,6 +15,7 @@ B=./fluidsolver_amd/bin/fs_bench
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $B 512 80 8 2 > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $B 512 80 8 2 > $OUT/pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o p -- $B 512 80 8 2 > $OUT/pmc_sq.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/pmc_sq2 -o p -- $B 512 80 8 2 > $OUT/pmc_sq2.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o p -- $B 512 80 8 2 > $OUT/pmc_l2.log 2>&1
 tail -1 $OUT/stats.log | cut -c1-400
 find $OUT -name "*.csv" | head -20
