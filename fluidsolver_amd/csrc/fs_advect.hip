@@ -47,11 +47,7 @@ __device__ __forceinline__ Axis split_axis(float x)
 // Math.cuh:57-60
 __device__ __forceinline__ float lerp1(float a, float b, float s)
 {
-#ifdef FS_FMA_EXPERIMENT
-    return __builtin_fmaf(a, 1.0f - s, b * s);
-#else
     return a * (1.0f - s) + b * s;
-#endif
 }
 
 // Solver.cu:109-112
@@ -414,24 +410,15 @@ __device__ __forceinline__ float3 rk4(const S& s, float3 pos, float dt, int& bad
 {
     float hdt = 0.5f * dt;
     float3 u1 = first ? *first : s.template vel<HALO>(pos, bad);
-#ifdef FS_FMA_EXPERIMENT
-#define FS_STEP(p, c, u) __builtin_fmaf(-(c), (u), (p))
-#define FS_ACC(a, u) __builtin_fmaf(2.0f, (u), (a))
-#else
-#define FS_STEP(p, c, u) ((p) - (c) * (u))
-#define FS_ACC(a, u) ((a) + 2.0f * (u))
-#endif
-    float3 p1 = make_float3(FS_STEP(pos.x, hdt, u1.x), FS_STEP(pos.y, hdt, u1.y), FS_STEP(pos.z, hdt, u1.z));
+    float3 p1 = make_float3(pos.x - hdt * u1.x, pos.y - hdt * u1.y, pos.z - hdt * u1.z);
     float3 u2 = s.template vel<HALO>(p1, bad);
-    float3 p2 = make_float3(FS_STEP(pos.x, hdt, u2.x), FS_STEP(pos.y, hdt, u2.y), FS_STEP(pos.z, hdt, u2.z));
+    float3 p2 = make_float3(pos.x - hdt * u2.x, pos.y - hdt * u2.y, pos.z - hdt * u2.z);
     float3 u3 = s.template vel<HALO>(p2, bad);
-    float3 p3 = make_float3(FS_STEP(pos.x, dt, u3.x), FS_STEP(pos.y, dt, u3.y), FS_STEP(pos.z, dt, u3.z));
+    float3 p3 = make_float3(pos.x - dt * u3.x, pos.y - dt * u3.y, pos.z - dt * u3.z);
     float3 u4 = s.template vel<HALO>(p3, bad);
-    float sx = FS_ACC(FS_ACC(u1.x, u2.x), u3.x) + u4.x;
-    float sy = FS_ACC(FS_ACC(u1.y, u2.y), u3.y) + u4.y;
-    float sz = FS_ACC(FS_ACC(u1.z, u2.z), u3.z) + u4.z;
-#undef FS_STEP
-#undef FS_ACC
+    float sx = ((u1.x + 2.0f * u2.x) + 2.0f * u3.x) + u4.x;
+    float sy = ((u1.y + 2.0f * u2.y) + 2.0f * u3.y) + u4.y;
+    float sz = ((u1.z + 2.0f * u2.z) + 2.0f * u3.z) + u4.z;
     return make_float3(pos.x - fsk::div6(dt * sx), pos.y - fsk::div6(dt * sy), pos.z - fsk::div6(dt * sz));
 }
 

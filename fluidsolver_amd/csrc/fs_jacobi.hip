@@ -554,11 +554,23 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
     // planes (a pass may only store planes it holds T input planes around, except at a wall)
     const int out_lo = g.z0 + (g.wall_lo ? 0 : kT), out_hi = g.z0 + g.nzl - (g.wall_hi ? 0 : kT);
     if (!can_block(g) || out_hi <= out_lo) return;
-    float *x = p, *y = np;
-    tune_tb(st, g, out_hi - out_lo, "jacobi_autotune", [&] {
-        launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
-        float* t = x; x = y; y = t;
-    });
+    // one timing per grid shape and process: solvers created later on the same shape take the
+    // remembered choice, so they cost no timing passes and run the same variant
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int>, std::pair<int, int>> tuned;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(g.nx, g.ny, g.nzl, g.wall_lo, g.wall_hi);
+    auto it = tuned.find(key);
+    if (it == tuned.end()) {
+        float *x = p, *y = np;
+        tune_tb(st, g, out_hi - out_lo, "jacobi_autotune", [&] {
+            launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
+            float* t = x; x = y; y = t;
+        });
+        it = tuned.emplace(key, std::make_pair(g.jacobi_tile, g.jacobi_lz)).first;
+    }
+    g.jacobi_tile = it->second.first;
+    g.jacobi_lz = it->second.second;
 }
 
 bool jacobi_can_block(const FsGrid& g) { return can_block(g); }
