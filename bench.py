@@ -120,7 +120,7 @@ def rocprof_kernel_name(stage, cfg, scheme, fused_div, slab):
     mac, halo = ("true" if scheme else "false"), ("true" if slab else "false")
     if stage == "jacobi":
         nty = cfg.get("tile_rows", 64)
-        return "k_jacobi_tb<0, 4, %d, 1, %d>" % (nty, cfg.get("aligned_rows", 0))
+        return "k_jacobi_tb<0, 4, %d, 1, %d, %d>" % (nty, cfg.get("aligned_rows", 0), cfg.get("nontemporal_stores", 0))
     if stage == "advect_velocity":
         return "k_advect_velocity_lds<DimsNarrow, %s, %s>" % (mac, halo)
     if stage == "advect_scalars":
@@ -349,7 +349,8 @@ def main():
             "jacobi_lups": (cells_rank * sweeps_done / (prof["jacobi"][0] * 1e-3)) if prof.get("jacobi", (0, 0))[0] > 0 else None,
             "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, sweeps_done / args.steps, n),
             "autotune": {"jacobi_tile_variant": cfg["variant"], "jacobi_tile_rows": cfg["tile_rows"],
-                         "jacobi_aligned_rows": cfg["aligned_rows"], "jacobi_planes_per_chunk": cfg["planes_per_chunk"]},
+                         "jacobi_aligned_rows": cfg["aligned_rows"], "jacobi_planes_per_chunk": cfg["planes_per_chunk"],
+                         "jacobi_nontemporal_stores": cfg["nontemporal_stores"]},
             "rccl_ranks": solver.comm_ranks if world > 1 else 0,
             "roofline": {
                 "stage": dom,

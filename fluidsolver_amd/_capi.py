@@ -118,7 +118,7 @@ def load_library():
     L.fs_residual.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.fs_residual_noalloc.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.fs_comm_ranks.argtypes = [vp]
-    L.fs_jacobi_config.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+    L.fs_jacobi_config.argtypes = [vp] + [C.POINTER(C.c_int)] * 5
     L.fs_cg_residual.argtypes = [vp, C.POINTER(C.c_float)]
     L.fs_profile_enable.argtypes = [vp, C.c_int]
     L.fs_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
@@ -284,10 +284,12 @@ class Solver:
         return out.value
 
     def jacobi_config(self):
-        """{variant, tile_rows, aligned_rows, planes_per_chunk} of the blocked Jacobi passes."""
-        v = [C.c_int() for _ in range(4)]
+        """{variant, tile_rows, aligned_rows, planes_per_chunk, nontemporal_stores} of the blocked
+        Jacobi passes."""
+        v = [C.c_int() for _ in range(5)]
         self._check(self._L.fs_jacobi_config(self._handle(), *[C.byref(x) for x in v]))
-        return dict(zip(("variant", "tile_rows", "aligned_rows", "planes_per_chunk"), (x.value for x in v)))
+        return dict(zip(("variant", "tile_rows", "aligned_rows", "planes_per_chunk", "nontemporal_stores"),
+                        (x.value for x in v)))
 
     @property
     def step_graphs(self):

@@ -153,7 +153,11 @@ enum { kJacobi = 0, kRbgs = 1, kRbgsZero = 2 };
 // ramp-up has reached them, or beyond a z wall): those results are never consumed by a plane that
 // is stored, they keep the register and LDS traffic on one fixed schedule, and the step body is
 // free of branches apart from the uniform wall fix-ups.
-template <int KIND, int T, int NTY, int CPT, int PH, int t>
+// NT: the stores of the last level carry the non-temporal cache policy (gfx950 cache-policy bit 1).
+// Measured at 512^3, where a field is larger than the Infinity Cache: 7.86 -> 7.56 ms per 80 sweeps;
+// at 256^3, where the three fields stay cache resident, it costs 12 %; on the loads it costs 10 % at
+// 512^3.  So it is one more candidate of the timing at creation, never a rule.
+template <int KIND, int T, int NTY, int CPT, int PH, int t, int NT>
 __device__ __forceinline__ void tb_level(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L, const TbArgs& A,
                                          const TbRange& Z, f4* lcur, const f4* lprv)
 {
@@ -206,13 +210,13 @@ __device__ __forceinline__ void tb_level(int n, TbRegs<T, CPT>& R, const TbLane<
             // plane 0 of level t: its z-1 neighbour (clamped / zero), for level t+1 at the next step
             if (k == 0) tb_plane<t, PH, -t - 1>(R, c) = KIND == kJacobi ? r : zero;
         } else if (k >= Z.out_lo && k < Z.out_hi) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), plane_rsrc(A.np, k, A), L.st_off[c], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), plane_rsrc(A.np, k, A), L.st_off[c], 0, NT ? 2 : 0);
         }
     }
 }
 
 // One march step; PH == (steps since the first one of this workgroup) mod 6.
-template <int KIND, int T, int NTY, int CPT, int PH, int... Ts>
+template <int KIND, int T, int NTY, int CPT, int PH, int NT, int... Ts>
 __device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<CPT>& L, const TbArgs& A,
                                         const TbRange& Z, f4* lds, std::integer_sequence<int, Ts...>)
 {
@@ -237,11 +241,11 @@ __device__ __forceinline__ void tb_step(int n, TbRegs<T, CPT>& R, const TbLane<C
         // plane 0: the clamped z-1 neighbour is the plane itself
         if (n == 0) R.w0[wrap(PH - 1, 3)][c] = KIND == kJacobi ? landed : f4{0.f, 0.f, 0.f, 0.f};
     }
-    (tb_level<KIND, T, NTY, CPT, PH, Ts + 1>(n, R, L, A, Z, lcur, lprv), ...);
+    (tb_level<KIND, T, NTY, CPT, PH, Ts + 1, NT>(n, R, L, A, Z, lcur, lprv), ...);
     __syncthreads();
 }
 
-template <int KIND, int T, int NTY, int CPT, int AX = 0>
+template <int KIND, int T, int NTY, int CPT, int AX = 0, int NT = 0>
 __global__ void __launch_bounds__(kW4 * NTY)
 k_jacobi_tb(TbArgs A)
 {
@@ -312,17 +316,17 @@ k_jacobi_tb(TbArgs A)
     const int last = Z.n_end + T;
     constexpr auto levels = std::make_integer_sequence<int, T>{};
     for (int n = Z.n_begin - 2;;) {
-        tb_step<KIND, T, NTY, CPT, 0>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 0, NT>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<KIND, T, NTY, CPT, 1>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 1, NT>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<KIND, T, NTY, CPT, 2>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 2, NT>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<KIND, T, NTY, CPT, 3>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 3, NT>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<KIND, T, NTY, CPT, 4>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 4, NT>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
-        tb_step<KIND, T, NTY, CPT, 5>(n, R, L, A, Z, lds, levels);
+        tb_step<KIND, T, NTY, CPT, 5, NT>(n, R, L, A, Z, lds, levels);
         if (++n >= last) break;
     }
 }
@@ -368,6 +372,13 @@ int tb_config(const FsGrid& g)
     }
     if (g.jacobi_tile > 0 && g.jacobi_tile <= kNumConfigs) return g.jacobi_tile - 1;
     return (long)g.nx * g.ny >= 224L * 224L ? 0 : 1;
+}
+
+// FS_JACOBI_NT = 0 / 1 forces the store policy (read per launch: tests switch it)
+int tb_nt(const FsGrid& g)
+{
+    if (const char* e = getenv("FS_JACOBI_NT")) return atoi(e) != 0;
+    return g.jacobi_nt;
 }
 
 int tb_order()
@@ -431,6 +442,12 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
     A.nblocks = A.tiles_x * A.tiles_y * chunks;
     A.order = tb_order();
     dim3 grid(A.nblocks), block(kW4, NTY);
+    if constexpr (KIND == kJacobi && T == kT) {
+        if (tb_nt(g)) {
+            hipLaunchKernelGGL((k_jacobi_tb<KIND, T, NTY, CPT, AX, 1>), grid, block, 0, st, A);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_jacobi_tb<KIND, T, NTY, CPT, AX>), grid, block, 0, st, A);
 }
 
@@ -482,10 +499,11 @@ int jacobi_block() { return kT; }
 // The timing loop: `pass()` launches one pass with g's current jacobi_tile / jacobi_lz over `nout`
 // output planes.  Leaves the winner in g (zeros = the rule and the cost model).
 template <class Pass>
-void tune_tb(hipStream_t st, FsGrid& g, int nout, const char* what, Pass&& pass)
+void tune_tb(hipStream_t st, FsGrid& g, int nout, const char* what, Pass&& pass, bool try_nt = false)
 {
     g.jacobi_tile = 0;
     g.jacobi_lz = 0;
+    g.jacobi_nt = 0;
     bool verbose = false;   // FS_JACOBI_TUNE=2 prints the readings
     if (const char* e = getenv("FS_JACOBI_TUNE")) {
         if (atoi(e) == 0) return;
@@ -538,9 +556,45 @@ void tune_tb(hipStream_t st, FsGrid& g, int nout, const char* what, Pass&& pass)
     if (failed || best_cfg < 0 || (rule_ms > 0.f && best > 0.97f * rule_ms)) {
         g.jacobi_tile = 0;
         g.jacobi_lz = 0;
+        best = rule_ms;
     } else {
         g.jacobi_tile = best_cfg + 1;
         g.jacobi_lz = best_lz;
+    }
+    // non-temporal stores on top of the choice so far (Jacobi passes only; pays where the fields
+    // do not fit the Infinity Cache)
+    if (try_nt && !failed && best > 0.f) {
+        // (the chunking is searched again: the policy shifts the best one, 2 -> 5 chunks at 512^3)
+        const int keep_lz = g.jacobi_lz;
+        float best_nt = -1.f;
+        int best_nt_lz = keep_lz;
+        g.jacobi_nt = 1;
+        for (int cc : chunk_counts) {
+            const int lz = cc ? cdiv(nout, cc) : keep_lz;
+            if (cc && (lz < 2 * kT || lz == keep_lz)) continue;
+            g.jacobi_lz = lz;
+            pass();
+            (void)hipEventRecord(a, st);
+            for (int i = 0; i < timed; ++i) pass();
+            (void)hipEventRecord(b, st);
+            float ms = 0.f;
+            if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) {
+                best_nt = -1.f;
+                break;
+            }
+            if (verbose) fprintf(stderr, "%s %dx%dx%d: non-temporal stores, %d planes per chunk: %.1f us per pass "
+                                 "(without: %.1f)\n", what, g.nx, g.ny, nout, lz, 1e3f * ms / timed, 1e3f * best / timed);
+            if (best_nt < 0.f || ms < best_nt) {
+                best_nt = ms;
+                best_nt_lz = lz;
+            }
+        }
+        if (best_nt > 0.f && best_nt <= 0.98f * best) {
+            g.jacobi_lz = best_nt_lz;
+        } else {
+            g.jacobi_nt = 0;
+            g.jacobi_lz = keep_lz;
+        }
     }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
@@ -550,6 +604,7 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
 {
     g.jacobi_tile = 0;
     g.jacobi_lz = 0;
+    g.jacobi_nt = 0;
     // what a slab's interior launch produces: planes whose T-sweep cone stays inside the owned
     // planes (a pass may only store planes it holds T input planes around, except at a wall)
     const int out_lo = g.z0 + (g.wall_lo ? 0 : kT), out_hi = g.z0 + g.nzl - (g.wall_hi ? 0 : kT);
@@ -557,7 +612,7 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
     // one timing per grid shape and process: solvers created later on the same shape take the
     // remembered choice, so they cost no timing passes and run the same variant
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int>, std::pair<int, int>> tuned;
+    static std::map<std::tuple<int, int, int, int, int>, std::tuple<int, int, int>> tuned;
     std::lock_guard<std::mutex> lock(mu);
     const auto key = std::make_tuple(g.nx, g.ny, g.nzl, g.wall_lo, g.wall_hi);
     auto it = tuned.find(key);
@@ -566,14 +621,17 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
         tune_tb(st, g, out_hi - out_lo, "jacobi_autotune", [&] {
             launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
             float* t = x; x = y; y = t;
-        });
-        it = tuned.emplace(key, std::make_pair(g.jacobi_tile, g.jacobi_lz)).first;
+        }, true);
+        it = tuned.emplace(key, std::make_tuple(g.jacobi_tile, g.jacobi_lz, g.jacobi_nt)).first;
     }
-    g.jacobi_tile = it->second.first;
-    g.jacobi_lz = it->second.second;
+    g.jacobi_tile = std::get<0>(it->second);
+    g.jacobi_lz = std::get<1>(it->second);
+    g.jacobi_nt = std::get<2>(it->second);
 }
 
 bool jacobi_can_block(const FsGrid& g) { return can_block(g); }
+
+int jacobi_nontemporal(const FsGrid& g) { return g.jacobi_nt; }
 
 void jacobi_config(const FsGrid& g, int* variant, int* rows, int* aligned, int* planes_per_chunk)
 {

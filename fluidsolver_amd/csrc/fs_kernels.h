@@ -23,6 +23,7 @@ struct FsGrid {
     int wall_hi;      // 1 if z0 + nzl is the global z = nz wall
     int jacobi_tile;  // 1 + tile variant of the blocked Jacobi kernel chosen for this grid, 0 = by rule
     int jacobi_lz;    // planes per z chunk of a blocked pass chosen for this grid, 0 = by the cost model
+    int jacobi_nt;    // 1 = the blocked Jacobi passes of this grid store with the non-temporal policy
 };
 
 struct FsFields {
@@ -109,6 +110,7 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
 // what the blocked passes of this grid run with: tile variant (-1 = the grid cannot block), its
 // tile rows, whether its output rows are 64-byte aligned, planes per z chunk (0 = cost model)
 void jacobi_config(const FsGrid& g, int* variant, int* rows, int* aligned, int* planes_per_chunk);
+int jacobi_nontemporal(const FsGrid& g);
 int jacobi_block();   // sweeps fused per pass
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
 int jacobi_launches(const FsGrid& g, int sweeps, int naive);

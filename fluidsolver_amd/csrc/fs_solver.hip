@@ -1108,7 +1108,8 @@ int fs_comm_ranks(const fs_solver* s)
     return n;
 }
 
-int fs_jacobi_config(const fs_solver* s, int* variant, int* tile_rows, int* aligned_rows, int* planes_per_chunk)
+int fs_jacobi_config(const fs_solver* s, int* variant, int* tile_rows, int* aligned_rows, int* planes_per_chunk,
+                     int* nontemporal_stores)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     int v, r, a, lz;
@@ -1117,6 +1118,7 @@ int fs_jacobi_config(const fs_solver* s, int* variant, int* tile_rows, int* alig
     if (tile_rows) *tile_rows = r;
     if (aligned_rows) *aligned_rows = a;
     if (planes_per_chunk) *planes_per_chunk = lz;
+    if (nontemporal_stores) *nontemporal_stores = fsk::jacobi_nontemporal(s->g);
     return FS_OK;
 }
 

@@ -155,9 +155,10 @@ FS_API int fs_slab_info(const fs_solver* s, int* rank, int* world, int* z0, int*
 FS_API int fs_comm_ranks(const fs_solver* s);
 /* What the temporally blocked Jacobi passes of this solver run with (chosen by timing at creation,
    no counterpart in the reference): tile variant 0..3 (-1 = this grid takes single sweeps only),
-   rows per tile, whether output rows are 64-byte aligned, planes per z chunk (0 = cost model). */
+   rows per tile, whether output rows are 64-byte aligned, planes per z chunk (0 = cost model),
+   whether the passes store with the non-temporal cache policy.  Any pointer may be NULL. */
 FS_API int fs_jacobi_config(const fs_solver* s, int* variant, int* tile_rows, int* aligned_rows,
-                            int* planes_per_chunk);
+                            int* planes_per_chunk, int* nontemporal_stores);
 
 /* -- stepping: replaces Solver::Update -> UpdateCuda (Solver.cu:1009-1114, 1132-1137)
       with VORT_CONFINE off and Project() on its Jacobi branch (Solver.cu:1178-1189) -- */
