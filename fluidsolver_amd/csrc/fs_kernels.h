@@ -16,7 +16,9 @@ struct FsGrid {
     int nx, ny, nz;   // global cell counts
     int z0;           // global index of the first owned cell plane
     int nzl;          // owned cell planes on this rank
-    int ghost;        // readable planes below z0 and above the last owned face plane
+    int ghost;        // planes below z0 and above the last owned face plane an advection gather may read
+    int pghost;       // ghost planes held per side (>= ghost): what the pressure, its divergence and the
+                      // velocity behind that divergence use on a slab
     int pitch;        // floats per row
     int plane;        // floats per z plane
     int wall_lo;      // 1 if z0 is the global z = 0 wall

@@ -168,7 +168,8 @@ struct fs_solver {
     int xchg_streams = -1;            // FS_XCHG_STREAMS: 1 / 0 force the two-stream / one-stream ordering
     char* h_stage[4] = {};            // pinned: send_lo, recv_lo, send_hi, recv_hi
     size_t h_stage_cap = 0;
-    bool vel_ghost_ok = false, scal_ghost_ok = false;
+    int vel_ghost = 0;                // valid ghost planes of the velocity on each side
+    bool scal_ghost_ok = false;
     bool div_fresh = false;           // div holds the divergence of the current velocity
     int p_ghost = 0;                  // valid ghost planes of p on each side
     bool halo_pending = false;        // an exchange is in flight; exchange_wait() orders the compute stream after it
@@ -193,8 +194,8 @@ struct fs_solver {
     // exchanges it contains are the ones that state asked for)
     struct HostState {
         FsFields f;
-        bool prev_held, vel_ghost_ok, scal_ghost_ok, div_fresh;
-        int p_ghost;
+        bool prev_held, scal_ghost_ok, div_fresh;
+        int vel_ghost, p_ghost;
     };
     struct StepGraph { HostState before, after; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
@@ -517,13 +518,13 @@ int exchange(fs_solver* s, const Seg* segs, int nseg)
     return rc ? rc : exchange_wait(s);
 }
 
-int ensure_velocity_ghosts(fs_solver* s)
+int ensure_velocity_ghosts(fs_solver* s, int planes)
 {
-    if (s->world == 1 || s->vel_ghost_ok) return FS_OK;
-    Seg segs[3] = {make_seg(s, s->f.ux, s->g.ghost, false), make_seg(s, s->f.uy, s->g.ghost, false),
-                   make_seg(s, s->f.uz, s->g.ghost, true)};
+    if (s->world == 1 || s->vel_ghost >= planes) return FS_OK;
+    Seg segs[3] = {make_seg(s, s->f.ux, planes, false), make_seg(s, s->f.uy, planes, false),
+                   make_seg(s, s->f.uz, planes, true)};
     int rc = exchange(s, segs, 3);
-    if (rc == FS_OK) s->vel_ghost_ok = true;
+    if (rc == FS_OK) s->vel_ghost = planes;
     return rc;
 }
 
@@ -542,7 +543,8 @@ int ensure_advect_ghosts(fs_solver* s)
     if (s->world == 1) return FS_OK;
     Seg segs[5];
     int n = 0;
-    if (!s->vel_ghost_ok) {
+    const bool vel = s->vel_ghost < s->g.ghost;
+    if (vel) {
         segs[n++] = make_seg(s, s->f.ux, s->g.ghost, false);
         segs[n++] = make_seg(s, s->f.uy, s->g.ghost, false);
         segs[n++] = make_seg(s, s->f.uz, s->g.ghost, true);
@@ -552,7 +554,10 @@ int ensure_advect_ghosts(fs_solver* s)
         segs[n++] = make_seg(s, s->f.rho, s->g.ghost, false);
     }
     int rc = exchange(s, segs, n);
-    if (rc == FS_OK) s->vel_ghost_ok = s->scal_ghost_ok = true;
+    if (rc == FS_OK) {
+        if (vel) s->vel_ghost = s->g.ghost;
+        s->scal_ghost_ok = true;
+    }
     return rc;
 }
 
@@ -562,7 +567,7 @@ int advect_ghosts_begin(fs_solver* s)
 {
     Seg segs[5];
     int n = 0;
-    if (!s->vel_ghost_ok) {
+    if (s->vel_ghost < s->g.ghost) {
         segs[n++] = make_seg(s, s->f.ux, s->g.ghost, false);
         segs[n++] = make_seg(s, s->f.uy, s->g.ghost, false);
         segs[n++] = make_seg(s, s->f.uz, s->g.ghost, true);
@@ -609,9 +614,47 @@ int run_jacobi(fs_solver* s, int sweeps)
         // ghost planes (what the gradient and the next step's first pass need).
         const int T = naive ? 1 : fsk::jacobi_block();
         const int z1 = g.z0 + g.nzl;
-        const bool split = !naive && fsk::jacobi_can_block(g) && g.nzl >= 2 * T + 1;
+        // (every rank must make the same sequence of exchanges, so the schedule is chosen by the
+        // thinnest slab of the decomposition, not by this rank's own)
+        const int thinnest = g.nz / s->world;
+        const bool split = !naive && fsk::jacobi_can_block(g) && thinnest >= 2 * T + 1;
+        // With ghost planes two passes deep, two passes share one exchange: pass A produces the
+        // slab and T planes beyond it from the 2T valid ghost planes (redundantly with the
+        // neighbour), pass B the slab itself, back in the buffer A read.  Boundary first again:
+        // A then B on the planes the neighbours need (and what those depend on), the exchange of
+        // the finished 2T planes, then A and B on the interior while they travel.  B's boundary
+        // output overwrites planes of the input buffer that A's interior launch no longer reads.
+        const bool pairs = split && g.pghost >= 2 * T && thinnest >= 6 * T + 1;
         int left = sweeps, launches = 0;
         StageScope sc(s, FS_STAGE_JACOBI, 0);
+        while (pairs && left >= 2 * T) {
+            int rc = ensure_p_ghosts(s, 2 * T);
+            if (rc) return rc;
+            float *p = s->f.p, *np = s->f.np;
+            const float* div = s->f.div;
+            const int inA_lo = g.wall_lo ? 0 : g.z0 - 2 * T, inA_hi = g.wall_hi ? g.nz : z1 + 2 * T;
+            const int inB_lo = g.wall_lo ? 0 : g.z0 - T, inB_hi = g.wall_hi ? g.nz : z1 + T;
+            // boundary ranges of A and B (empty at a global wall), then their interiors
+            const int a_lo0 = g.z0 - T, a_lo1 = g.wall_lo ? a_lo0 : g.z0 + 3 * T;
+            const int a_hi1 = z1 + T, a_hi0 = g.wall_hi ? a_hi1 : z1 - 3 * T;
+            const int b_lo0 = g.z0, b_lo1 = g.wall_lo ? b_lo0 : g.z0 + 2 * T;
+            const int b_hi1 = z1, b_hi0 = g.wall_hi ? b_hi1 : z1 - 2 * T;
+            FS_TRACE(s, "launch Jacobi pair, boundary planes");
+            fsk::jacobi_pass(s->st, g, p, np, div, T, inA_lo, inA_hi, a_lo0, a_lo1, a_hi0, a_hi1);
+            fsk::jacobi_pass(s->st, g, np, p, div, T, inB_lo, inB_hi, b_lo0, b_lo1, b_hi0, b_hi1);
+            xmark(s, s->st, "Jacobi pair, boundary planes");
+            Seg seg = make_seg(s, p, 2 * T, false);
+            rc = exchange_begin(s, &seg, 1);
+            if (rc) return rc;
+            FS_TRACE(s, "launch Jacobi pair, interior planes");
+            fsk::jacobi_pass(s->st, g, p, np, div, T, inA_lo, inA_hi, g.wall_lo ? g.z0 : a_lo1, g.wall_hi ? z1 : a_hi0);
+            fsk::jacobi_pass(s->st, g, np, p, div, T, inB_lo, inB_hi, g.wall_lo ? g.z0 : b_lo1, g.wall_hi ? z1 : b_hi0);
+            xmark(s, s->st, "Jacobi pair, interior planes");
+            s->p_ghost = 2 * T;
+            s->prev_held = false;
+            launches += 4;
+            left -= 2 * T;
+        }
         while (left > 0) {
             int t = left < T ? left : T;
             int rc = ensure_p_ghosts(s, t);
@@ -791,7 +834,16 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     if (world > 1 && (p->flags & FS_FLAG_VORT_CONFINE))
         return fail(FS_ERR_INVALID, "fs_create_slab: FS_FLAG_VORT_CONFINE is single-GPU only (its gathers "
                                     "mix z planes through mismatched strides)");
+    // planes an advection gather may reach into a neighbour's slab / ghost planes held per side.
+    // A slab holds twice the depth of a fused Jacobi pass where it is thick enough: two passes then
+    // share one exchange (FS_SLAB_PGHOST=4 keeps one exchange per pass).
     const int ghost = world > 1 ? 4 : 2;
+    int pghost = ghost;
+    if (world > 1) {
+        const char* e = getenv("FS_SLAB_PGHOST");
+        const int want = e ? atoi(e) : 8;
+        if (want >= 8 && p->nz / world >= 9) pghost = 8;
+    }
     // z-slabs: the first nz % world ranks get one plane more
     const int base = p->nz / world, extra = p->nz % world;
     const int nzl = base + (rank < extra ? 1 : 0);
@@ -837,6 +889,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     g.z0 = z0;
     g.nzl = nzl;
     g.ghost = ghost;
+    g.pghost = pghost;
     g.wall_lo = rank == 0;
     g.wall_hi = rank == world - 1;
     // an odd multiple of 16 floats: consecutive rows start in alternate halves of a 128-byte
@@ -844,9 +897,9 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     g.pitch = round_up(p->nx + 3, 16);
     if (g.pitch % 32 == 0) g.pitch += 16;
     long long plane = (long long)g.pitch * (p->ny + 3);
-    long long planes = (long long)g.nzl + 1 + 2 * g.ghost;
+    long long planes = (long long)g.nzl + 1 + 2 * g.pghost;
     // kernels index with 32-bit element offsets relative to global plane 0
-    if (plane * ((long long)p->nz + g.ghost + 2) >= (1LL << 31)) {
+    if (plane * ((long long)p->nz + g.pghost + 2) >= (1LL << 31)) {
         delete s;
         return fail(FS_ERR_INVALID, "fs_create: %dx%dx%d needs more than 2^31 elements per field",
                     p->nx, p->ny, p->nz);
@@ -854,7 +907,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     g.plane = (int)plane;
     // slack so that (x,y,z) = (-2,-2,z0-ghost) is addressable, kept 256-byte aligned
     size_t slack = (size_t)round_up(2 * g.pitch + 2, 64);
-    s->origin = slack + (size_t)g.ghost * plane;
+    s->origin = slack + (size_t)g.pghost * plane;
     s->field_elems = (slack + (size_t)(planes * plane) + 63) / 64 * 64;
 
     const int nfields = 13;
@@ -921,7 +974,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         // Solver.cu:993-995: T = temperature_env (ghost planes too: they hold the same constant)
         if (p->temperature_env != 0.f) {
             FsGrid all = g;
-            const int lo = g.wall_lo ? 0 : g.ghost, hi = g.wall_hi ? 0 : g.ghost;
+            const int lo = g.wall_lo ? 0 : g.pghost, hi = g.wall_hi ? 0 : g.pghost;
             all.nzl = g.nzl + lo + hi;
             fsk::fill_interior(s->st, all, s->f.T - (ptrdiff_t)lo * g.plane, p->temperature_env);
         }
@@ -966,8 +1019,9 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         // all fields are zero here: let the blocked Jacobi kernel pick its tile variant on this grid
         fsk::jacobi_autotune(s->st, g, s->f.p, s->f.np, s->f.div);
         // zero state: every ghost plane already equals its neighbour's owned plane
-        s->vel_ghost_ok = s->scal_ghost_ok = true;
-        s->p_ghost = g.ghost;
+        s->vel_ghost = g.pghost;
+        s->scal_ghost_ok = true;
+        s->p_ghost = g.pghost;
         s->eager_steps_left = world > 1 ? 2 : 0;
         if (hipStreamSynchronize(s->st) != hipSuccess || hipGetLastError() != hipSuccess) {
             rc = fail(FS_ERR_HIP, "fs_create: initialisation kernels failed");
@@ -1141,7 +1195,7 @@ int fs_stage_force(fs_solver* s)
     FS_HIP(hipSetDevice(s->device));
     StageScope sc(s, FS_STAGE_FORCE, 1);
     fsk::force_uy(s->st, s->g, s->f.uy, s->f.T, s->prm.dt, s->prm.temperature_env);
-    s->vel_ghost_ok = false;
+    s->vel_ghost = 0;
     s->div_fresh = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -1166,7 +1220,7 @@ int fs_stage_confine(fs_solver* s)
     StageScope sc(s, FS_STAGE_CONFINE, 3);
     fsk::vort_confine(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->vort[0], s->vort[1], s->vort[2],
                       s->prm.curl_strength);
-    s->vel_ghost_ok = false;
+    s->vel_ghost = 0;
     s->div_fresh = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -1200,7 +1254,8 @@ static int stage_advect(fs_solver* s, bool fuse_div)
         fsk::advect_velocity(s->st, g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag, z0 + m_lo,
                              z1 - m_hi + (g.wall_hi ? 1 : 0), true);
         if ((rc = exchange_wait(s))) return rc;
-        s->vel_ghost_ok = s->scal_ghost_ok = true;
+        if (s->vel_ghost < g.ghost) s->vel_ghost = g.ghost;
+        s->scal_ghost_ok = true;
         fsk::advect_velocity(s->st, g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag, z0, z0 + m_lo);
         if (!g.wall_hi)
             fsk::advect_velocity(s->st, g, f.nux, f.nuy, f.nuz, f.ux, f.uy, f.uz, dt, sc, s->d_flag, z1 - m_hi,
@@ -1209,25 +1264,27 @@ static int stage_advect(fs_solver* s, bool fuse_div)
     std::swap(f.ux, f.nux);
     std::swap(f.uy, f.nuy);
     std::swap(f.uz, f.nuz);
-    s->vel_ghost_ok = false;
+    s->vel_ghost = 0;
     // Solver.cu:1160-1164: T then rho with the NEW (advected, unprojected) velocity.  The kernel
     // also leaves the divergence of the new velocity behind for the owned cells, unless the
     // confinement force is still to change that velocity.
     float* div = (fuse_div && !(s->prm.flags & FS_FLAG_VORT_CONFINE)) ? f.div : nullptr;
     if (!split) {
-        if ((rc = ensure_velocity_ghosts(s))) return rc;
+        // (the same planes a splitting neighbour trades at this point: pghost of them)
+        if ((rc = ensure_velocity_ghosts(s, g.pghost))) return rc;
         StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 1);
         s->div_fresh = fsk::advect_scalars(s->st, g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc,
                                            s->d_flag, div);
     } else {
         StageScope ps(s, FS_STAGE_ADVECT_SCALARS, 3);
-        Seg segs[3] = {make_seg(s, f.ux, g.ghost, false), make_seg(s, f.uy, g.ghost, false),
-                       make_seg(s, f.uz, g.ghost, true)};
+        // (pghost planes: the divergence the pressure passes need beyond the slab comes from them)
+        Seg segs[3] = {make_seg(s, f.ux, g.pghost, false), make_seg(s, f.uy, g.pghost, false),
+                       make_seg(s, f.uz, g.pghost, true)};
         if ((rc = exchange_begin(s, segs, 3))) return rc;
         bool fresh = fsk::advect_scalars(s->st, g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag,
                                          div, z0 + m_lo, z1 - m_hi, true);
         if ((rc = exchange_wait(s))) return rc;
-        s->vel_ghost_ok = true;
+        s->vel_ghost = g.pghost;
         fresh &= fsk::advect_scalars(s->st, g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag, div,
                                      z0, z0 + m_lo);
         fresh &= fsk::advect_scalars(s->st, g, f.T, f.nT, f.rho, f.nrho, f.ux, f.uy, f.uz, dt, sc, s->d_flag, div,
@@ -1254,11 +1311,11 @@ int fs_stage_divergence(fs_solver* s)
     const FsGrid& g = s->g;
     int zb = g.z0, ze = g.z0 + g.nzl;
     if (s->world > 1) {
-        // the fused Jacobi pass recomputes intermediate sweeps on the ghost planes, so div is
-        // needed jacobi_block()-1 planes beyond the slab; the velocity ghosts provide it
-        int rc = ensure_velocity_ghosts(s);
+        // the fused Jacobi passes recompute sweeps on the ghost planes of the pressure, so div is
+        // needed pghost - 1 planes beyond the slab; the velocity ghosts provide it
+        int rc = ensure_velocity_ghosts(s, g.pghost);
         if (rc) return rc;
-        const int ext = fsk::jacobi_block() - 1;
+        const int ext = g.pghost - 1;
         if (!g.wall_lo) zb -= ext;
         if (!g.wall_hi) ze += ext;
     }
@@ -1320,7 +1377,7 @@ int fs_stage_gradient(fs_solver* s)
     if (rc) return rc;
     StageScope sc(s, FS_STAGE_GRADIENT, 1);
     fsk::gradient(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->f.p);
-    s->vel_ghost_ok = false;
+    s->vel_ghost = 0;
     s->div_fresh = false;
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -1346,14 +1403,14 @@ static int step_eager(fs_solver* s)
 
 static fs_solver::HostState host_state(const fs_solver* s)
 {
-    return {s->f, s->prev_held, s->vel_ghost_ok, s->scal_ghost_ok, s->div_fresh, s->p_ghost};
+    return {s->f, s->prev_held, s->scal_ghost_ok, s->div_fresh, s->vel_ghost, s->p_ghost};
 }
 
 static void set_host_state(fs_solver* s, const fs_solver::HostState& h)
 {
     s->f = h.f;
     s->prev_held = h.prev_held;
-    s->vel_ghost_ok = h.vel_ghost_ok;
+    s->vel_ghost = h.vel_ghost;
     s->scal_ghost_ok = h.scal_ghost_ok;
     s->div_fresh = h.div_fresh;
     s->p_ghost = h.p_ghost;
@@ -1365,7 +1422,7 @@ static bool same_launches(const fs_solver* s, const fs_solver::HostState& a, con
 {
     if (std::memcmp(&a.f, &b.f, sizeof(FsFields)) != 0) return false;
     if (s->world == 1) return true;
-    return a.vel_ghost_ok == b.vel_ghost_ok && a.scal_ghost_ok == b.scal_ghost_ok && a.p_ghost == b.p_ghost &&
+    return a.vel_ghost == b.vel_ghost && a.scal_ghost_ok == b.scal_ghost_ok && a.p_ghost == b.p_ghost &&
            a.div_fresh == b.div_fresh;
 }
 
@@ -1610,7 +1667,7 @@ int fs_field_upload(fs_solver* s, int field, const float* src)
     if (!s || !src || field < 0 || field >= FS_NUM_FIELDS)
         return fail(FS_ERR_INVALID, "fs_field_upload: bad argument");
     FS_HIP(hipSetDevice(s->device));
-    if (field <= FS_UZ) s->vel_ghost_ok = false;
+    if (field <= FS_UZ) s->vel_ghost = 0;
     if (field <= FS_UZ || field == FS_DIV) s->div_fresh = false;
     if (field == FS_RHO || field == FS_T) s->scal_ghost_ok = false;
     if (field == FS_P) s->p_ghost = 0;
@@ -1624,7 +1681,7 @@ int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layout)
     *ptr = *field_slot(s, field);
     // the caller may write through the pointer: forget what was derived from these fields
     if (field <= FS_UZ || field == FS_DIV) s->div_fresh = false;
-    if (field <= FS_UZ) s->vel_ghost_ok = false;
+    if (field <= FS_UZ) s->vel_ghost = 0;
     if (field == FS_RHO || field == FS_T) s->scal_ghost_ok = false;
     if (field == FS_P) s->p_ghost = 0;
     if (layout) {
@@ -1633,7 +1690,7 @@ int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layout)
         layout->dz = s->g.nz + (field == FS_UZ);
         layout->z0 = s->g.z0;
         layout->nz_local = s->g.nzl + ((field == FS_UZ) ? 1 : 0);
-        layout->ghost = s->g.ghost;
+        layout->ghost = s->g.pghost;
         layout->pitch = (size_t)s->g.pitch;
         layout->plane = (size_t)s->g.plane;
     }

@@ -81,6 +81,19 @@ def test_slab_boundary_launch_with_several_chunks_per_range(cfg):
               {"FS_JACOBI_CFG": str(cfg), "FS_JACOBI_LZ": "2", "FS_JACOBI_TUNE": "0"})
 
 
+@pytest.mark.parametrize("pghost", [8, 4])
+@pytest.mark.parametrize("world,dims,steps,k", [
+    (2, (36, 28, 56), 3, 20),     # 28 planes per rank: two pairs of passes and a single pass per step
+    (3, (68, 40, 81), 2, 19),     # interior rank with two neighbours; pairs, then 3 sweeps in one pass
+])
+def test_slab_paired_passes_share_one_exchange(world, dims, steps, k, pghost):
+    """Slabs of at least 25 planes hold 8 ghost planes of the pressure and run the fused Jacobi
+    passes in pairs with one exchange per pair (pass A also produces 4 planes of each neighbour's
+    slab); FS_SLAB_PGHOST=4 keeps one exchange per pass on the same grids."""
+    run_ranks(world, ["host", *dims, steps, k, "random"], 29720 + world + pghost,
+              {"FS_SLAB_PGHOST": str(pghost), "FS_JACOBI_TUNE": "0"})
+
+
 def test_slab_one_stream_ordering_fallback():
     """FS_XCHG_STREAMS=0: the fall-back ordering with every transfer on the compute stream (no
     overlap) gives the same fields."""
