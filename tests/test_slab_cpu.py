@@ -3,7 +3,8 @@
 No GPU here, so the HIP kernels cannot run; what these tests pin is the decomposition itself --
 which ghost planes are refreshed when, and how wide -- by replaying the library's orchestration
 (fluidsolver_amd/csrc/fs_solver.hip: ensure_advect_ghosts / ensure_velocity_ghosts /
-run_jacobi's split passes with one exchange of 4 planes after each, extended divergence range) with the CPU
+run_jacobi's split passes with one exchange of 4 planes after each or, on slabs of 25 planes and more,
+its pairs of passes with one exchange of 8 planes per pair, extended divergence range) with the CPU
 oracle's kernels.  Every rank keeps full-size arrays but only its owned + ghost planes hold data;
 everything else is poisoned with NaN after each exchange, so any read beyond the ghost planes,
 and any stale ghost, shows up as a mismatch against the single-domain oracle.  The same file
@@ -64,14 +65,17 @@ def _exchange(dist, arrays, planes, z0, z1, rank, world, face_flags):
         a[sl] = recv.numpy()
 
 
-def _poison(a, z0, z1, face, rank, world):
-    lo = 0 if rank == 0 else z0 - GHOST
-    hi = a.shape[0] if rank == world - 1 else z1 + (1 if face else 0) + GHOST
+def _poison(a, z0, z1, face, rank, world, depth=GHOST):
+    lo = 0 if rank == 0 else z0 - depth
+    hi = a.shape[0] if rank == world - 1 else z1 + (1 if face else 0) + depth
     a[:max(lo, 0)] = np.nan
     a[hi:] = np.nan
 
 
 def _slab_worker(rank, world, port, dims, steps, k, result):
+    # ghost planes held for the pressure, its divergence and the velocity behind it (create_common)
+    pghost = 2 * BLOCK if dims[2] // world >= 2 * BLOCK + 1 else GHOST
+    pairs = pghost >= 2 * BLOCK and dims[2] // world >= 6 * BLOCK + 1
     import torch.distributed as dist
     import oracle
     from fluidsolver_amd.slab import slab_range
@@ -98,10 +102,10 @@ def _slab_worker(rank, world, port, dims, steps, k, result):
         def refresh(arrs, planes, faces):
             _exchange(dist, arrs, planes, z0, z1, rank, world, faces)
             for a, f in zip(arrs, faces):
-                _poison(a, z0, z1, f, rank, world)
+                _poison(a, z0, z1, f, rank, world, planes)
 
         ok = True
-        p_ghost = GHOST      # all-zero initial pressure: the ghost planes are valid
+        p_ghost = pghost     # all-zero initial pressure: the ghost planes are valid
         for step in range(steps):
             ref.step()
             oracle.source(rho, T, par.source_x, par.source_y, par.source_z, par.source_radius, par.rho0, par.temperature0)
@@ -111,14 +115,32 @@ def _slab_worker(rank, world, port, dims, steps, k, result):
             nuy = own(uy, oracle.semilag(uy, ux, uy, uz, par.dt, 2))
             nuz = own(uz, oracle.semilag(uz, ux, uy, uz, par.dt, 3), face=True)
             ux, uy, uz = nux, nuy, nuz
-            refresh([ux, uy, uz], GHOST, [False, False, True])                           # ensure_velocity_ghosts
+            refresh([ux, uy, uz], pghost, [False, False, True])                          # new velocity: pghost planes
             T = own(T, oracle.semilag(T, ux, uy, uz, par.dt, 0))
             rho = own(rho, oracle.semilag(rho, ux, uy, uz, par.dt, 0))
             div = oracle.divergence(ux, uy, uz)
-            lo = 0 if rank == 0 else z0 - (BLOCK - 1)
-            hi = nz if rank == world - 1 else z1 + (BLOCK - 1)
+            lo = 0 if rank == 0 else z0 - (pghost - 1)
+            hi = nz if rank == world - 1 else z1 + (pghost - 1)
             div[:lo] = np.nan; div[hi:] = np.nan                                         # extended divergence range
             left = k
+            while pairs and left >= 2 * BLOCK:
+                if p_ghost < 2 * BLOCK:
+                    refresh([p], 2 * BLOCK, [False])                                     # ensure_p_ghosts(2T)
+                # pass A: the slab and BLOCK planes beyond it; pass B: the slab
+                for reach in (2 * BLOCK, BLOCK):
+                    plo = 0 if rank == 0 else z0 - reach
+                    phi = nz if rank == world - 1 else z1 + reach
+                    q = p.copy(); q[:plo] = np.nan; q[phi:] = np.nan
+                    for _ in range(BLOCK):
+                        q, _r = oracle.jacobi(q, div, want_r=False)
+                    keep = reach - BLOCK
+                    olo = 0 if rank == 0 else z0 - keep
+                    ohi = nz if rank == world - 1 else z1 + keep
+                    p = p.copy(); p[olo:ohi] = q[olo:ohi]
+                    p[:olo] = np.nan; p[ohi:] = np.nan
+                refresh([p], 2 * BLOCK, [False])                                         # one exchange per pair
+                p_ghost = 2 * BLOCK
+                left -= 2 * BLOCK
             while left > 0:
                 t = min(BLOCK, left)
                 if p_ghost < t:
@@ -195,7 +217,8 @@ def _spawn(fn, world, *args):
     assert list(result) == [1] * world, list(result)
 
 
-@pytest.mark.parametrize("world,dims,steps,k", [(2, (16, 12, 20), 4, 10), (3, (12, 12, 27), 3, 7)])
+@pytest.mark.parametrize("world,dims,steps,k", [(2, (16, 12, 20), 4, 10), (3, (12, 12, 27), 3, 7),
+                                                (2, (10, 8, 52), 2, 20)])   # 26 planes per rank: paired passes
 def test_slab_decomposition_replay_matches_single_domain(world, dims, steps, k):
     os.environ.setdefault("OMP_NUM_THREADS", "2")
     _spawn(_slab_worker, world, dims, steps, k)
