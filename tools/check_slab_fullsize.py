@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""One-off parity check of a z-slab run at a BASELINE size against the CPU oracle.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node W --master-addr 127.0.0.1 \
+        --master-port P tools/check_slab_fullsize.py NX NY NZ STEPS SWEEPS [tolerance]
+
+W ranks share whatever GPUs the box has (host-staged halos over gloo, the transport of the test
+suite).  Rank 0 alone steps the single-domain oracle (minutes per step at 512 x 512 x 1024) and
+broadcasts each of its fields; every rank compares its own planes bit for bit.  With a tolerance
+the step runs in convergence mode (sum r^2 all-reduced every 8 sweeps) and the oracle repeats the
+sweep count the slabs report.  Too slow for the test suite; its output is kept under profiles/.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(1100, exit=True)
+    import torch
+    import torch.distributed as dist
+    import fluidsolver_amd as fs
+    from fluidsolver_amd.slab import SlabSolver
+
+    nx, ny, nz, steps, k = (int(v) for v in sys.argv[1:6])
+    tol = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kw = dict(jacobi_iters=k)
+    if tol > 0:
+        kw.update(tolerance=tol, check_every=8, max_sweeps=k)
+    s = SlabSolver(fs.default_params(nx, ny, nz, device=dev, **kw), rank, world, transport="host").Initialize()
+    o = None
+    if rank == 0:
+        import oracle
+        o = oracle.Oracle(oracle.default_params(nx, ny, nz, jacobi_iters=k))
+    ok = True
+    for step in range(steps):
+        t0 = time.perf_counter()
+        s.step()
+        s.sync()
+        t_gpu = time.perf_counter() - t0
+        sweeps = s.last_sweeps
+        t0 = time.perf_counter()
+        if rank == 0:
+            if tol > 0:
+                import oracle
+                o.stage("source"); o.stage("force"); o.stage("advect")
+                d = oracle.divergence(o.get(0), o.get(1), o.get(2))
+                pp = o.get(5)
+                for _ in range(sweeps):
+                    pp, _r = oracle.jacobi(pp, d, want_r=False)
+                o.set(5, pp); o.set(6, d)
+                o.stage("gradient")
+            else:
+                o.step()
+        t_cpu = time.perf_counter() - t0
+        bad = 0
+        for fid in range(6):
+            shape = fs.field_shape(fid, nx, ny, nz)
+            want = torch.from_numpy(np.ascontiguousarray(o.get(fid))) if rank == 0 else torch.empty(shape, dtype=torch.float32)
+            dist.broadcast(want, src=0)
+            got = s.field(fid)
+            mine = want.numpy()[s.z0:s.z0 + got.shape[0]]
+            n = int((got != mine).sum())
+            if n:
+                print("rank %d step %d field %s: %d of %d values differ" % (rank, step + 1, fs.FIELD_NAMES[fid], n, got.size),
+                      flush=True)
+                bad += n
+        flag = torch.tensor([bad])
+        dist.all_reduce(flag)
+        ok = ok and int(flag.item()) == 0
+        if rank == 0:
+            print("step %d: %d sweeps, slabs %.2f s (first step includes creation effects), oracle %.1f s, "
+                  "mismatching values over all ranks and fields: %d" % (step + 1, sweeps, t_gpu, t_cpu, int(flag.item())),
+                  flush=True)
+    s.close()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("%dx%dx%d on %d ranks, %d steps, %s: %s" % (nx, ny, nz, world, steps,
+              ("convergence mode, tolerance %g" % tol) if tol > 0 else "%d sweeps" % k,
+              "BIT-IDENTICAL to the oracle" if ok else "MISMATCH"), flush=True)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
     for (int i = 0; i < iters; ++i) {
         f2 a = rd<MODE>(addr), b = rd<MODE>(addr + 4096 * 4), c = rd<MODE>(addr + 8), d = rd<MODE>(addr + 4096 * 4 + 8);
         f2 e = rd<MODE>(addr + 16), f = rd<MODE>(addr + 4096 * 4 + 16), g = rd<MODE>(addr + 24), h = rd<MODE>(addr + 4096 * 4 + 24);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the registers are operands of the wait, so that no use of them can be scheduled above it
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)::"memory");
         acc += a + b + c + d + e + f + g + h;
         asm volatile("" : "+v"(addr));
     }
