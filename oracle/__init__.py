@@ -54,6 +54,7 @@ def lib():
         return _lib
     build()
     L = C.CDLL(_LIB_PATH)
+    L.fso_set_fmad.argtypes = [C.c_int]
     L.fso_default_params.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
     L.fso_create.argtypes = [C.POINTER(Params)]
     L.fso_create.restype = C.c_void_p
@@ -132,6 +133,11 @@ def field_shape(which, nx, ny, nz):
     if which in (VORTX, VORTY, VORTZ):
         return ((nz + 1) * (ny + 1) * (nx + 1),)      # flat: written and read with different strides
     return (nz, ny, nx)
+
+
+def set_fmad(on):
+    """Process-wide contraction switch of the oracle (see fso_set_fmad); always reset it to False."""
+    lib().fso_set_fmad(1 if on else 0)
 
 
 def default_params(nx, ny, nz, **kw):

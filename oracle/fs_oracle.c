@@ -73,10 +73,35 @@ static inline float cg_sample(const float* field, i3 pos, i3 max_pos)
     return field[flat(pos, max_pos)];
 }
 
+/* Contraction sensitivity switch (fso_set_fmad).  The reference is built by nvcc, whose default
+   -fmad=true fuses a multiply into a following add or subtract wherever it likes; which of them it
+   fuses is not determined by the source, so the oracle's contract is the uncontracted meaning
+   (g_fmad = 0).  With g_fmad = 1 the expressions of the advection and the buoyancy that have the
+   shape x*y + z or z - x*y are evaluated with one fused multiply-add the way LLVM-based compilers
+   contract them (the left product of a sum of two products is the fused one).  No GPU kernel has
+   this mode; tests use it only to measure how far contraction can move the fields. */
+static int g_fmad = 0;
+void fso_set_fmad(int on) { g_fmad = on != 0; }
+
 /* Math.cuh:57-60 */
 static inline float lerpf(float a, float b, float s)
 {
+    if (g_fmad) return fmaf(a, 1 - s, b * s);
     return a * (1 - s) + b * s;
+}
+
+/* pos - c * u of the RK stages (Solver.cu:145, 150, 155) and a + 2 * u of :160 */
+static inline f3 f3_step(f3 pos, float c, f3 u)
+{
+    if (g_fmad) { pos.x = fmaf(-c, u.x, pos.x); pos.y = fmaf(-c, u.y, pos.y); pos.z = fmaf(-c, u.z, pos.z); return pos; }
+    pos.x -= c * u.x; pos.y -= c * u.y; pos.z -= c * u.z;
+    return pos;
+}
+static inline f3 f3_add2(f3 a, f3 u)
+{
+    if (g_fmad) { a.x = fmaf(2.0f, u.x, a.x); a.y = fmaf(2.0f, u.y, a.y); a.z = fmaf(2.0f, u.z, a.z); return a; }
+    a.x += 2.0f * u.x; a.y += 2.0f * u.y; a.z += 2.0f * u.z;
+    return a;
 }
 
 /* Math.cuh:80-118 float3 operators, spelled out so the association is explicit */
@@ -148,15 +173,16 @@ static f3 RK4(const float* ux, const float* uy, const float* uz, f3 pos, float d
               int nx, int ny, int nz)
 {
     f3 u1 = velocity_at(ux, uy, uz, pos, nx, ny, nz);
-    f3 p1 = f3_sub(pos, f3_scale(0.5f * dt, u1));                 /* :145 */
+    /* (f3_step(pos, c, u) is f3_sub(pos, f3_scale(c, u)) unless the contraction switch is on) */
+    f3 p1 = f3_step(pos, 0.5f * dt, u1);                          /* :145 */
     f3 u2 = velocity_at(ux, uy, uz, p1, nx, ny, nz);
-    f3 p2 = f3_sub(pos, f3_scale(0.5f * dt, u2));                 /* :150 */
+    f3 p2 = f3_step(pos, 0.5f * dt, u2);                          /* :150 */
     f3 u3 = velocity_at(ux, uy, uz, p2, nx, ny, nz);
-    f3 p3 = f3_sub(pos, f3_scale(dt, u3));                        /* :155 */
+    f3 p3 = f3_step(pos, dt, u3);                                 /* :155 */
     f3 u4 = velocity_at(ux, uy, uz, p3, nx, ny, nz);
     /* :160  pos - dt * (u1 + 2.0*u2 + 2.0*u3 + u4) / 6.0 ; the double literals
        convert to float through the operator signatures (Math.cuh:80,112). */
-    f3 sum = f3_add(f3_add(f3_add(u1, f3_scale(2.0f, u2)), f3_scale(2.0f, u3)), u4);
+    f3 sum = f3_add(f3_add2(f3_add2(u1, u2), u3), u4);   /* ((u1 + 2 u2) + 2 u3) + u4 */
     return f3_sub(pos, f3_div(f3_scale(dt, sum), 6.0f));
 }
 
@@ -224,6 +250,10 @@ void fso_force_uy(float* uy, const float* temperature_field, float dt, float tem
                 size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * (ny + 1);
                 f3 pos = mk_f3((float)i + 0.5f, (float)j, (float)k + 0.5f);
                 float temperature = trilerp(temperature_field, pos, 0.5f, 0.5f, 0.5f, max_pos, 1);
+                if (g_fmad) {
+                    uy[ind] = fmaf(temperature - temperature_env, dt, uy[ind]);
+                    continue;
+                }
                 float buoyancy = (temperature - temperature_env) * dt;
                 uy[ind] += buoyancy;
             }

@@ -35,6 +35,10 @@ typedef struct fso_params {
 
 typedef struct fso_state fso_state;
 
+/* 1: evaluate the x*y + z shaped expressions of the advection and the buoyancy with fused
+   multiply-adds, as nvcc's default -fmad=true may (process-wide; default 0 = the uncontracted
+   meaning every GPU kernel implements).  For sensitivity tests only. */
+void fso_set_fmad(int on);
 void fso_default_params(fso_params* p, int nx, int ny, int nz);
 fso_state* fso_create(const fso_params* p);
 void fso_destroy(fso_state* s);

@@ -337,3 +337,32 @@ def test_mgpcg_solves_the_system_and_keeps_the_pointer_quirk(oracle):
     o.close()
     with pytest.raises(MemoryError):                 # dims must be multiples of 2^(levels-1)
         oracle.Oracle(oracle.default_params(12, 24, 16, **kw))
+
+
+def test_contraction_sensitivity_of_the_64_cube_configuration(oracle):
+    """How far can fused multiply-adds move the fields?  The reference is built by nvcc, whose
+    default -fmad=true contracts x*y + z wherever it likes; the oracle (and every GPU kernel)
+    evaluates the uncontracted expressions.  BASELINE configuration 1 (64^3, 100 steps, 20 sweeps)
+    stepped both ways: the density stays within the 1e-4 the north-star allows, the velocity
+    components do not (a few 1e-3 of their maxima after 100 steps).  So agreement with a reference
+    BINARY to 1e-4 on velocity would need its exact contraction pattern, which the source does not
+    determine; what this repository pins is bit-equality with the uncontracted meaning."""
+    def run(fmad):
+        oracle.set_fmad(fmad)
+        try:
+            o = oracle.Oracle(oracle.default_params(64, 64, 64, jacobi_iters=20))
+            o.step(100)
+            out = [o.get(f).copy() for f in range(5)]
+            o.close()
+        finally:
+            oracle.set_fmad(False)
+        return out
+    strict, fused = run(False), run(True)
+    rel = [float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(strict, fused)]
+    ux, uy, uz, rho, T = rel
+    assert 0 < rho < 2e-4 and 0 < T < 2e-4          # measured 9.4e-5
+    assert max(ux, uy, uz) < 2e-2                    # measured 3.7e-3, 6.8e-4, 2.8e-3
+    assert max(ux, uy, uz) > 1e-4                    # the point of the test: contraction is visible
+    # and the switch is really off again: a strict run reproduces itself
+    again = run(False)
+    assert all(np.array_equal(a, b) for a, b in zip(strict, again))
