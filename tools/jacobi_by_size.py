@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Rate of the blocked Jacobi passes on grids whose three pressure fields do or do not fit the
+256 MiB Infinity Cache (512 x 512 x 64 = 192 MiB does, 512^3 = 1.5 GiB does not): cell-sweeps per
+second, device time per fused pass and the variant the creation-time timing picked.
+
+    python tools/jacobi_by_size.py
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fluidsolver_amd as fs
