@@ -136,9 +136,11 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
 // (zin_is_zero: zin holds zeros and is not read)
 bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases,
                bool zin_is_zero = false);
-// Vorticity confinement (single slab only).  The three vorticity arrays are dense, vort_elems(g)
-// floats each, zero-filled once by the owner.
+// Vorticity confinement.  The three vorticity arrays are dense, vort_elems(g) floats each, zero-filled
+// once by the owner; on a slab they are this rank's window of the global flat index space: its
+// cells plus vort_halo_planes(g) planes of nx*ny entries per side, which the neighbours fill.
 size_t vort_elems(const FsGrid& g);
+int vort_halo_planes(const FsGrid& g);
 void find_vort(hipStream_t st, const FsGrid& g, float* vortx, float* vorty, float* vortz, const float* ux,
                const float* uy, const float* uz);
 void vort_confine(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* vortx,

@@ -831,9 +831,18 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     }
     if ((p->flags & FS_FLAG_TEST_SELF_PEER) && world < 2)
         return fail(FS_ERR_INVALID, "fs_create: FS_FLAG_TEST_SELF_PEER is a test hook of z-slabs");
-    if (world > 1 && (p->flags & FS_FLAG_VORT_CONFINE))
-        return fail(FS_ERR_INVALID, "fs_create_slab: FS_FLAG_VORT_CONFINE is single-GPU only (its gathers "
-                                    "mix z planes through mismatched strides)");
+    if (world > 1 && (p->flags & FS_FLAG_VORT_CONFINE)) {
+        // the confinement gathers land up to this many xy-planes above a rank's own entries of the
+        // vorticity arrays (mismatched strides, see fs_vort.hip); they must come from the direct
+        // neighbour
+        FsGrid probe{};
+        probe.nx = p->nx; probe.ny = p->ny; probe.nz = p->nz;
+        const int h = fsk::vort_halo_planes(probe);
+        if (h > p->nz / world)
+            return fail(FS_ERR_INVALID, "fs_create_slab: FS_FLAG_VORT_CONFINE on %dx%dx%d needs %d planes of the "
+                                        "upper neighbour's vorticity, slabs of %d ranks hold only %d",
+                        p->nx, p->ny, p->nz, h, world, p->nz / world);
+    }
     // planes an advection gather may reach into a neighbour's slab / ghost planes held per side.
     // A slab holds twice the depth of a fused Jacobi pass where it is thick enough: two passes then
     // share one exchange (FS_SLAB_PGHOST=4 keeps one exchange per pass).
@@ -1206,9 +1215,34 @@ int fs_stage_vorticity(fs_solver* s)
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     if (!(s->prm.flags & FS_FLAG_VORT_CONFINE)) return FS_OK;
     FS_HIP(hipSetDevice(s->device));
+    if (s->world > 1) {
+        // the curl at a rank's lowest cells reads the velocity one plane below them: the exchange
+        // the advection is about to ask for anyway
+        int rc = ensure_advect_ghosts(s);
+        if (rc) return rc;
+    }
     StageScope sc(s, FS_STAGE_VORTICITY, 1);
     fsk::find_vort(s->st, s->g, s->vort[0], s->vort[1], s->vort[2], s->f.ux, s->f.uy, s->f.uz);
     FS_HIP(hipGetLastError());
+    if (s->world > 1) {
+        // fill the halo planes of the windows: the first / last h planes of every rank's own entries
+        // go to the lower / upper neighbour (planes of nx*ny entries; see fs_vort.hip)
+        const FsGrid& g = s->g;
+        const size_t cell = (size_t)g.nx * g.ny;
+        const int h = fsk::vort_halo_planes(g);
+        const size_t own = (size_t)(g.wall_lo ? 0 : h) * cell;   // offset of this rank's first own entry
+        Seg segs[3];
+        for (int q = 0; q < 3; ++q) {
+            float* base = s->vort[q] + own;
+            segs[q].n = (size_t)h * cell;
+            segs[q].send_lo = g.wall_lo ? nullptr : base;
+            segs[q].recv_lo = g.wall_lo ? nullptr : s->vort[q];
+            segs[q].send_hi = g.wall_hi ? nullptr : base + (size_t)(g.nzl - h) * cell;
+            segs[q].recv_hi = g.wall_hi ? nullptr : base + (size_t)g.nzl * cell;
+        }
+        int rc = exchange(s, segs, 3);
+        if (rc) return rc;
+    }
     return FS_OK;
 }
 

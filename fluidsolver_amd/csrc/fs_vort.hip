@@ -1,4 +1,4 @@
-// fs_vort.hip -- vorticity confinement (optional stage, single GPU), defined-behaviour variant.
+// fs_vort.hip -- vorticity confinement (optional stage), defined-behaviour variant.
 //
 // Reference: CuSolver/Source/Solver.cu FindVortx/y/z :485-525 (launched :1035-1037, before the
 // advection) and ApplyVortConfinement :540-605 (launched :1078-1080, after it).  The reference
@@ -11,6 +11,11 @@
 // the double-precision sqrt(... + 1e-5) (:593), true divisions.
 //
 // The arrays are dense (no row padding): the reference's flat indices are used as they are.
+// On a z-slab a rank holds the window of that flat index space its own faces can reach (its
+// cells' entries plus halo_planes() xy-planes of nx*ny entries on each side, filled by the
+// neighbours): a gather at face (i, j, k) lands up to (j + k) / ny entries-planes above plane k
+// because of the mismatched strides.  The pointers the kernels receive are offset so that the
+// global flat index addresses the window.
 #include "fs_kernels.h"
 
 #pragma clang fp contract(off)
@@ -33,11 +38,11 @@ __device__ __forceinline__ float vel(const float* __restrict__ f, int x, int y, 
 // Solver.cu:485-525, all three components in one pass
 __global__ void k_find_vort(float* __restrict__ vortx, float* __restrict__ vorty, float* __restrict__ vortz,
                             const float* __restrict__ ux, const float* __restrict__ uy,
-                            const float* __restrict__ uz, int nx, int ny, int nz, int pitch, int plane)
+                            const float* __restrict__ uz, int nx, int ny, int nz, int pitch, int plane, int zb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = blockIdx.z;
+    const int k = zb + blockIdx.z;
     if (i >= nx || j >= ny) return;
     const size_t ind = (size_t)i + (size_t)j * nx + (size_t)k * nx * ny;
     {   // :492-496
@@ -145,11 +150,11 @@ __device__ __forceinline__ float vort_norm(const VortView& vx, const VortTaps& t
 // component, which are also the reference's launch dims, so the guard of :548 is literal.
 template <int DIR>
 __global__ void k_vort_confine(float* __restrict__ u, VortView vx, VortView vy, VortView vz, int dx, int dy,
-                               int dz, int pitch, int plane, float coeff)
+                               int dz, int pitch, int plane, float coeff, int zb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = blockIdx.z;
+    const int k = zb + blockIdx.z;
     if (!(i > 2 && i < dx - 2 && j > 2 && j < dy - 2 && k > 2 && k < dz - 2)) return;
     constexpr int PX = DIR == 1 ? 0 : 1, PY = DIR == 2 ? 0 : 1, PZ = DIR == 3 ? 0 : 1;
     const VortTaps tx = make_taps(vx, i, j, k), ty = make_taps(vy, i, j, k), tz = make_taps(vz, i, j, k);
@@ -181,36 +186,63 @@ __global__ void k_vort_confine(float* __restrict__ u, VortView vx, VortView vy, 
 
 namespace fsk {
 
-size_t vort_elems(const FsGrid& g) { return (size_t)(g.nx + 1) * (size_t)(g.ny + 1) * (size_t)(g.nz + 1); }
+// xy-planes (nx*ny entries each) of the vorticity arrays a rank needs beyond its own cells: one
+// below (the z - 1 taps), and above as far as the largest flat index the gathers of its topmost
+// faces form, (z1 + 1) * (nx+1)(ny+1) + ..., exceeds z1 * nx*ny.  One figure for all ranks (the
+// topmost one's), so every exchange has the same size.
+int vort_halo_planes(const FsGrid& g)
+{
+    const long long cell = (long long)g.nx * g.ny;
+    const long long top = ((long long)g.nz + 2) * ((long long)g.nx + 1) * ((long long)g.ny + 1);
+    return (int)((top - (long long)g.nz * cell + cell - 1) / cell);
+}
+
+// entries one array of this rank holds: its cells, the halo planes on each non-wall side and,
+// at the upper wall, what the single-domain layout holds beyond the cells
+size_t vort_elems(const FsGrid& g)
+{
+    const size_t cell = (size_t)g.nx * g.ny;
+    const int h = vort_halo_planes(g);
+    return cell * ((size_t)g.nzl + (g.wall_lo ? 0 : h) + h);
+}
+
+// flat index of the first entry held
+size_t vort_first(const FsGrid& g)
+{
+    return (size_t)g.nx * g.ny * (size_t)(g.z0 - (g.wall_lo ? 0 : vort_halo_planes(g)));
+}
 
 void find_vort(hipStream_t st, const FsGrid& g, float* vortx, float* vorty, float* vortz, const float* ux,
                const float* uy, const float* uz)
 {
-    dim3 block(64, 4), grid(cdiv(g.nx, 64), cdiv(g.ny, 4), g.nz);
-    hipLaunchKernelGGL(k_find_vort, grid, block, 0, st, vortx, vorty, vortz, ux, uy, uz, g.nx, g.ny, g.nz,
-                       g.pitch, g.plane);
+    // this rank's cells; the window pointers and the velocity take global indices
+    const ptrdiff_t w = (ptrdiff_t)vort_first(g), zoff = (ptrdiff_t)g.z0 * g.plane;
+    dim3 block(64, 4), grid(cdiv(g.nx, 64), cdiv(g.ny, 4), g.nzl);
+    hipLaunchKernelGGL(k_find_vort, grid, block, 0, st, vortx - w, vorty - w, vortz - w, ux - zoff, uy - zoff,
+                       uz - zoff, g.nx, g.ny, g.nz, g.pitch, g.plane, g.z0);
 }
 
 void vort_confine(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* vortx,
                   const float* vorty, const float* vortz, float coeff)
 {
-    const VortView vx{vortx, g.nx, g.ny + 1, g.nz + 1}, vy{vorty, g.nx + 1, g.ny, g.nz + 1},
-        vz{vortz, g.nx + 1, g.ny + 1, g.nz};
+    const ptrdiff_t w = (ptrdiff_t)vort_first(g), zoff = (ptrdiff_t)g.z0 * g.plane;
+    const VortView vx{vortx - w, g.nx, g.ny + 1, g.nz + 1}, vy{vorty - w, g.nx + 1, g.ny, g.nz + 1},
+        vz{vortz - w, g.nx + 1, g.ny + 1, g.nz};
     dim3 block(64, 4);
     {
         const int dx = g.nx + 1, dy = g.ny, dz = g.nz;
-        hipLaunchKernelGGL(k_vort_confine<1>, dim3(cdiv(dx, 64), cdiv(dy, 4), dz), block, 0, st, ux, vx, vy, vz,
-                           dx, dy, dz, g.pitch, g.plane, coeff);
+        hipLaunchKernelGGL(k_vort_confine<1>, dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl), block, 0, st, ux - zoff, vx, vy,
+                           vz, dx, dy, dz, g.pitch, g.plane, coeff, g.z0);
     }
     {
         const int dx = g.nx, dy = g.ny + 1, dz = g.nz;
-        hipLaunchKernelGGL(k_vort_confine<2>, dim3(cdiv(dx, 64), cdiv(dy, 4), dz), block, 0, st, uy, vx, vy, vz,
-                           dx, dy, dz, g.pitch, g.plane, coeff);
+        hipLaunchKernelGGL(k_vort_confine<2>, dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl), block, 0, st, uy - zoff, vx, vy,
+                           vz, dx, dy, dz, g.pitch, g.plane, coeff, g.z0);
     }
-    {
+    {   // the face plane shared with the upper neighbour is produced by both ranks
         const int dx = g.nx, dy = g.ny, dz = g.nz + 1;
-        hipLaunchKernelGGL(k_vort_confine<3>, dim3(cdiv(dx, 64), cdiv(dy, 4), dz), block, 0, st, uz, vx, vy, vz,
-                           dx, dy, dz, g.pitch, g.plane, coeff);
+        hipLaunchKernelGGL(k_vort_confine<3>, dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl + 1), block, 0, st, uz - zoff, vx,
+                           vy, vz, dx, dy, dz, g.pitch, g.plane, coeff, g.z0);
     }
 }
 

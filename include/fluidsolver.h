@@ -61,7 +61,9 @@ enum {
        advection (Solver.cu:1078-1080).  The reference gathers from its vorticity arrays beyond
        their allocation (Solver.cu:556-558 against :894-896); this build gives the same index
        arithmetic arrays of (nx+1)(ny+1)(nz+1) zero-initialised floats, so every read is defined.
-       Single GPU only. */
+       On z-slabs every rank holds its window of those arrays plus a halo from its neighbours
+       (the mismatched strides make a gather land up to about 2 + (nx + ny) nz / (nx ny) planes
+       above its face; fs_create_slab refuses decompositions whose slabs are thinner than that). */
     FS_FLAG_VORT_CONFINE = 1 << 2,
     /* Test hook of z-slabs: the slab keeps its place in the decomposition but both neighbours are
        the rank itself (RCCL transport: its communicator holds this rank alone; host-staged

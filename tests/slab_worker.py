@@ -138,9 +138,13 @@ def main():
         kw["flags"] = fs.FS_FLAG_JACOBI_NAIVE
     if "converge" in extra:
         kw.update(tolerance=1e-3, check_every=8, max_sweeps=400)
+    if "confine" in extra:
+        kw["flags"] = kw.get("flags", 0) | fs.FS_FLAG_VORT_CONFINE
     p = fs.default_params(nx, ny, nz, device=dev, **kw)
     s = SlabSolver(p, rank, world, transport=mode).Initialize()
     okw = {a: b for a, b in kw.items() if a not in ("flags", "tolerance", "check_every", "max_sweeps")}
+    if "confine" in extra:
+        okw["vort_confine"] = 1
     o = oracle.Oracle(oracle.default_params(nx, ny, nz, **okw))
     ok = True
     if "random" in extra:

@@ -304,17 +304,6 @@ def test_vorticity_confinement_full_steps(fs, oracle):
     g.close(); o.close()
 
 
-def test_vorticity_confinement_rejected_on_slabs(fs):
-    import ctypes as C
-    L = fs.load_library()
-    p = fs.default_params(16, 16, 32, flags=fs.FS_FLAG_VORT_CONFINE)
-    h = C.c_void_p()
-    cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)(
-        lambda *a: 0)
-    rc = L.fs_create_slab(C.byref(p), 0, 2, None, cb, None, C.byref(h))
-    assert rc == -1 and b"single-GPU" in L.fs_last_error()
-
-
 @pytest.mark.parametrize("cfg", [0, 1, 2])
 def test_jacobi_division_on_hard_inputs(fs, oracle, cfg, monkeypatch):
     """The fused kernel divides by 6 through a binary64 multiply; the oracle uses the true
