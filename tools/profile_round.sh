@@ -12,6 +12,18 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench512 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/stats.log 2>&1
 B=./fluidsolver_amd/bin/fs_bench
+# the counter passes run the tile variant, chunking and store policy the bench run above timed as
+# best (its JSON line names them), not whatever a timing under the profiler would pick
+eval $(python3 - "$OUT/stats.log" <<'PY'
+import json, sys
+line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
+a = json.loads(line)["autotune"]
+print("export FS_JACOBI_TUNE=0 FS_JACOBI_CFG=%d FS_JACOBI_NT=%d" % (max(a["jacobi_tile_variant"], 0), a["jacobi_nontemporal_stores"]))
+if a["jacobi_planes_per_chunk"] > 0:
+    print("export FS_JACOBI_LZ=%d" % a["jacobi_planes_per_chunk"])
+PY
+)
+echo "counter passes with FS_JACOBI_CFG=$FS_JACOBI_CFG FS_JACOBI_LZ=$FS_JACOBI_LZ FS_JACOBI_NT=$FS_JACOBI_NT"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $B 512 80 8 2 > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $B 512 80 8 2 > $OUT/pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o p -- $B 512 80 8 2 > $OUT/pmc_sq.log 2>&1
