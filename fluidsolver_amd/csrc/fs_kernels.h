@@ -131,6 +131,15 @@ void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const
                       float alpha, double* partial, double* out);
 float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, float* zalt, int levels,
                        int init_smooth_steps, int bottom_smooth_steps);   // returns z or zalt: the result
+// The same operations on a z-slab's windows of the levels (dense nx x ny x held arrays that hold the
+// owned planes plus ghost planes; see fs_mgpcg.hip): one colour of the smoother (kpar = parity of the
+// global index of the window's plane 0), restriction into the cz owned coarse planes (fk0 = fine
+// window plane of the lower children of the first of them), prolongation over every fine plane whose
+// parent the coarse window holds (f0 / c0 = global index of the fine / coarse window's plane 0).
+void mgs_smooth_phase(hipStream_t st, const float* r, float* z, int nx, int ny, int held, int phase, int kpar);
+void mgs_restrict(hipStream_t st, const float* rf, const float* zf, int nx, int ny, int held_f, int fk0,
+                  float* rc_owned, int cz);
+void mgs_prolongate(hipStream_t st, float* zf, int nx, int ny, int held_f, int f0, const float* zc, int c0, int cheld);
 // `phases` (2 or 4) red/black Gauss-Seidel half-sweeps of the zero-outside operator on a dense
 // nx x ny x nz array in one blocked pass, zin -> zout; false if the grid cannot take it
 // (zin_is_zero: zin holds zeros and is not read)

@@ -88,10 +88,11 @@ __global__ void k_update_p(float* __restrict__ p, const float* __restrict__ z, f
 
 // One colour of red/black Gauss-Seidel: a thread per cell of that colour (the cells of the other
 // colour are only read, so the sweep is race-free and order-independent).
-__global__ void k_smooth(const float* __restrict__ r, float* z, int phase, Dim3i d)
+// (kpar: parity of the global z index of the array's plane 0 -- non-zero only for a slab's window)
+__global__ void k_smooth(const float* __restrict__ r, float* z, int phase, Dim3i d, int kpar)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-    const int i = 2 * t + ((j + k + phase) & 1);
+    const int i = 2 * t + ((j + k + kpar + phase) & 1);
     if (i >= d.x || j >= d.y) return;
     const size_t ind = (size_t)i + (size_t)j * d.x + (size_t)k * d.x * d.y;
     z[ind] = fsk::div6(r[ind] + neibor_sum(z, i, j, k, d));
@@ -154,6 +155,47 @@ __global__ void k_prolongate(float* __restrict__ z, const float* __restrict__ zc
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
     if (i >= d.x || j >= d.y) return;
     const size_t cind = (size_t)(i >> 1) + (size_t)(j >> 1) * (d.x >> 1) + (size_t)(k >> 1) * (d.x >> 1) * (d.y >> 1);
+    z[(size_t)i + (size_t)j * d.x + (size_t)k * d.x * d.y] += zc[cind];
+}
+
+// ---- z-slab windows -------------------------------------------------------------------------------
+// On a slab a rank holds, of every level, the planes it owns plus ghost planes of its neighbours,
+// as one dense array that the kernels above treat as a whole grid: beyond the array they read zero,
+// which is the operator's boundary value at a global wall and a wrong value at a slab face.  That
+// error enters the outermost ghost plane and moves one plane inward per stencil application; the
+// driver (fs_solver.hip) refreshes the ghost planes before it can reach an owned plane.
+
+// Restriction (the eight SubRestrict launches, as k_restrict) into the OWNED planes of the coarse
+// window: fine plane fk0 + 2*ck holds the lower children of owned coarse plane ck.
+__global__ void k_restrict_win(const float* __restrict__ r, const float* __restrict__ z, float* __restrict__ rc,
+                               Dim3i d, int fk0, int cz)
+{
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x, cj = blockIdx.y * blockDim.y + threadIdx.y, ck = blockIdx.z;
+    const int cx = d.x / 2, cy = d.y / 2;
+    if (ci >= cx || cj >= cy || ck >= cz) return;
+    const size_t cind = (size_t)ci + (size_t)cj * cx + (size_t)ck * cx * cy;
+    float acc = rc[cind];
+#pragma unroll
+    for (int phase = 0; phase < 8; ++phase) {
+        const int i = ci * 2 + (phase & 1), j = cj * 2 + ((phase >> 1) & 1), k = fk0 + ck * 2 + ((phase >> 2) & 1);
+        const size_t ind = (size_t)i + (size_t)j * d.x + (size_t)k * d.x * d.y;
+        const float res = r[ind] - (6 * z[ind] - neibor_sum(z, i, j, k, d));
+        acc = (float)((double)acc + (double)res * 0.5);
+    }
+    rc[cind] = acc;
+}
+
+// Prolongation over every plane of the fine window whose parent plane the coarse window holds:
+// fine plane k is global plane f0 + k, its parent global plane (f0 + k) >> 1 = coarse plane
+// ((f0 + k) >> 1) - c0 of the coarse window (cheld planes).
+__global__ void k_prolongate_win(float* __restrict__ z, const float* __restrict__ zc, Dim3i d, int f0, int c0,
+                                 int cheld)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+    if (i >= d.x || j >= d.y) return;
+    const int ck = ((f0 + k) >> 1) - c0;
+    if (ck < 0 || ck >= cheld) return;
+    const size_t cind = (size_t)(i >> 1) + (size_t)(j >> 1) * (d.x >> 1) + (size_t)ck * (d.x >> 1) * (d.y >> 1);
     z[(size_t)i + (size_t)j * d.x + (size_t)k * d.x * d.y] += zc[cind];
 }
 
@@ -465,7 +507,7 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
         }
         for (int i = 0; i < phases; ++i)   // red, black, red, ... (phases is even here)
             hipLaunchKernelGGL(k_smooth, dim3(cdiv(cdiv(d.x, 2), 32), cdiv(d.y, 4), d.z), dim3(32, 4), 0, st,
-                               r + offset, cur[l], i & 1, d);
+                               r + offset, cur[l], i & 1, d, 0);
     };
     for (; l < levels - 1; ++l) {
         cur[l] = z + offset; alt[l] = zalt + offset;
@@ -490,6 +532,29 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
         smooth(init_smooth_steps << l, false);
     }
     return cur[0];
+}
+
+// ---- launchers for the z-slab windows (dense arrays of nx x ny x held planes) ------------------------
+
+void mgs_smooth_phase(hipStream_t st, const float* r, float* z, int nx, int ny, int held, int phase, int kpar)
+{
+    const Dim3i d{nx, ny, held};
+    hipLaunchKernelGGL(k_smooth, dim3(cdiv(cdiv(nx, 2), 32), cdiv(ny, 4), held), dim3(32, 4), 0, st, r, z, phase & 1, d,
+                       kpar & 1);
+}
+
+void mgs_restrict(hipStream_t st, const float* rf, const float* zf, int nx, int ny, int held_f, int fk0,
+                  float* rc_owned, int cz)
+{
+    const Dim3i d{nx, ny, held_f};
+    hipLaunchKernelGGL(k_restrict_win, dim3(cdiv(nx / 2, 32), cdiv(ny / 2, 4), cz), dim3(32, 4), 0, st, rf, zf, rc_owned,
+                       d, fk0, cz);
+}
+
+void mgs_prolongate(hipStream_t st, float* zf, int nx, int ny, int held_f, int f0, const float* zc, int c0, int cheld)
+{
+    const Dim3i d{nx, ny, held_f};
+    hipLaunchKernelGGL(k_prolongate_win, grid3(d), dim3(64, 4), 0, st, zf, zc, d, f0, c0, cheld);
 }
 
 }  // namespace fsk

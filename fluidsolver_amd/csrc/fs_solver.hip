@@ -139,6 +139,19 @@ struct fs_solver {
     float *cg_r = nullptr, *cg_z = nullptr, *cg_zalt = nullptr, *cg_p = nullptr, *cg_Ap = nullptr, *cg_x = nullptr;
     double *cg_partial = nullptr, *cg_out = nullptr;
     double* h_dot = nullptr;          // pinned
+    // MGPCG on a z-slab: this rank's window of every level (owned planes plus mg_G ghost planes per
+    // non-wall side) inside the dense work arrays; vz = ghost planes of z that are exact right now
+    struct MgWin {
+        int nx, ny, nz;    // global dims of the level
+        int z0, nzl;       // owned planes
+        int lo, hi;        // ghost planes held below / above
+        size_t off;        // offset of the window inside r and z
+        int vz;
+        size_t cell() const { return (size_t)nx * ny; }
+        int held() const { return lo + nzl + hi; }
+    };
+    std::vector<MgWin> mgw;
+    int mg_G = 0;
     bool cg_x_is_pressure = false;    // the reference's member x has become the pressure buffer
     float cg_rtr = 0.f;
     size_t field_elems = 0;           // floats per field including slack and ghost planes
@@ -776,6 +789,167 @@ int run_mgpcg(fs_solver* s)
     return FS_OK;
 }
 
+// ---- MGPCG on z-slabs ------------------------------------------------------------------------------
+// Every kernel runs on the rank's whole window of a level, ghost planes included, and reads zero
+// beyond it: exact at a global wall, wrong at a slab face, where the error enters the outermost
+// ghost plane and moves one plane inward per stencil application.  The driver counts the ghost
+// planes that are still exact (MgWin::vz) and refreshes them from the neighbours' owned planes
+// before an owned plane could be touched.  The count follows the same rule on every rank (walls
+// are not special-cased), so all ranks make the same sequence of exchanges.
+
+// the sum over all ranks of the double a kernel pair has left in cg_out, narrowed to the float the
+// reference's host logic works with (synchronises)
+int cg_read_sum_all(fs_solver* s, float* out)
+{
+    if (s->comm) {
+        Rccl* R = rccl();
+        FS_NCCL(R->AllReduce(s->cg_out, s->cg_out, 1, ncclDouble, ncclSum, s->comm, s->st));
+    }
+    FS_HIP(hipMemcpyAsync(s->h_dot, s->cg_out, sizeof(double), hipMemcpyDeviceToHost, s->st));
+    FS_HIP(hipStreamSynchronize(s->st));
+    if (!s->comm) {
+        int rc = s->xfn(s->xctx, FS_XCHG_SUM_F64, s->h_dot, nullptr, nullptr, nullptr, sizeof(double));
+        if (rc) return fail(FS_ERR_COMM, "rank %d: the all-reduce callback returned %d", s->rank, rc);
+    }
+    *out = (float)*s->h_dot;
+    return FS_OK;
+}
+
+// refresh `planes` ghost planes of a window array (base = its first held plane) of level l
+int mg_exchange(fs_solver* s, float* base, int l, int planes)
+{
+    const fs_solver::MgWin& W = s->mgw[l];
+    const size_t c = W.cell();
+    Seg g;
+    g.n = (size_t)planes * c;
+    float* own = base + (size_t)W.lo * c;
+    g.send_lo = W.lo ? own : nullptr;
+    g.recv_lo = W.lo ? own - (size_t)planes * c : nullptr;
+    g.send_hi = W.hi ? own + (size_t)(W.nzl - planes) * c : nullptr;
+    g.recv_hi = W.hi ? own + (size_t)W.nzl * c : nullptr;
+    return exchange(s, &g, 1);
+}
+
+// `steps` red/black sweeps of level l (Smooth, Solver.cu:848-860), one launch per colour
+int mg_smooth_slab(fs_solver* s, int l, int steps, bool from_zero)
+{
+    fs_solver::MgWin& W = s->mgw[l];
+    float *r = s->cg_r + W.off, *z = s->cg_z + W.off;
+    const int G = s->mg_G, kpar = (W.z0 - W.lo) & 1;
+    for (int ph = 0; ph < 2 * steps; ++ph) {
+        if (from_zero && ph == 0) {
+            W.vz = G;   // z = 0 is exact everywhere, and so is the first colour computed from it
+        } else {
+            if (W.vz < 1) {
+                int rc = mg_exchange(s, z, l, G);
+                if (rc) return rc;
+                W.vz = G;
+            }
+            W.vz -= 1;
+        }
+        fsk::mgs_smooth_phase(s->st, r, z, W.nx, W.ny, W.held(), ph, kpar);
+    }
+    return FS_OK;
+}
+
+// one V-cycle (MG_Preconditioner, Solver.cu:1312-1366): level 0 of r (ghost planes exact) -> level 0 of z
+int mg_precondition_slab(fs_solver* s)
+{
+    const fs_params& P = s->prm;
+    const int L = P.mg_level, G = s->mg_G;
+    // z of every level and the coarse levels of r start at zero
+    {
+        const fs_solver::MgWin& W0 = s->mgw[0];
+        const size_t n0 = W0.cell() * W0.held(), space = s->mgw[L - 1].off + s->mgw[L - 1].cell() * s->mgw[L - 1].held();
+        FS_HIP(hipMemsetAsync(s->cg_z, 0, space * sizeof(float), s->st));
+        if (space > n0) FS_HIP(hipMemsetAsync(s->cg_r + n0, 0, (space - n0) * sizeof(float), s->st));
+    }
+    int rc;
+    for (int l = 0; l < L - 1; ++l) {
+        fs_solver::MgWin &W = s->mgw[l], &C = s->mgw[l + 1];
+        if ((rc = mg_smooth_slab(s, l, P.init_smooth_steps << l, true))) return rc;
+        // the residual of a child needs z one plane beyond it
+        if (W.vz < 1) {
+            if ((rc = mg_exchange(s, s->cg_z + W.off, l, G))) return rc;
+            W.vz = G;
+        }
+        fsk::mgs_restrict(s->st, s->cg_r + W.off, s->cg_z + W.off, W.nx, W.ny, W.held(), W.lo,
+                          s->cg_r + C.off + (size_t)C.lo * C.cell(), C.nzl);
+        // the coarse right-hand side of the ghost planes comes from the ranks that own them
+        if ((rc = mg_exchange(s, s->cg_r + C.off, l + 1, G))) return rc;
+    }
+    if ((rc = mg_smooth_slab(s, L - 1, P.bottom_smooth_steps, true))) return rc;
+    for (int l = L - 2; l >= 0; --l) {
+        fs_solver::MgWin &W = s->mgw[l], &C = s->mgw[l + 1];
+        fsk::mgs_prolongate(s->st, s->cg_z + W.off, W.nx, W.ny, W.held(), W.z0 - W.lo, s->cg_z + C.off, C.z0 - C.lo,
+                            C.held());
+        // a fine ghost plane d planes out has its parent ceil(d/2) planes out
+        W.vz = W.vz < 2 * C.vz ? W.vz : 2 * C.vz;
+        if ((rc = mg_smooth_slab(s, l, P.init_smooth_steps << l, false))) return rc;
+    }
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+// Conjugate(f_pressure, f_div), Solver.cu:1226-1297, on this rank's slab
+int run_mgpcg_slab(fs_solver* s)
+{
+    const FsGrid& g = s->g;
+    const fs_params& P = s->prm;
+    StageScope sc(s, FS_STAGE_MGPCG, 1);
+    const fs_solver::MgWin& W = s->mgw[0];
+    const size_t cell = W.cell(), own = (size_t)W.lo * cell;
+    float *r = s->cg_r, *z = s->cg_z, *p = s->cg_p, *Ap = s->cg_Ap, *x = s->cg_x;
+    // the window as a grid of its own (what the element-wise and operator kernels see), and its
+    // owned planes (what the dot products sum over)
+    FsGrid gw = g, go = g;
+    gw.nz = W.held();
+    go.nz = W.nzl;
+    auto dot = [&](const float* a, const float* b, float* out) {
+        fsk::cg_dot(s->st, go, a + own, b + own, s->cg_partial, s->cg_out);
+        return cg_read_sum_all(s, out);
+    };
+    int rc = FS_OK;
+    // r = -div on every held plane (the divergence is exact pghost - 1 planes beyond the slab), x = 0
+    fsk::cg_init(s->st, gw, r, x, s->f.div - (ptrdiff_t)W.lo * g.plane);               // :1233
+    if (g.pghost - 1 < s->mg_G && (rc = mg_exchange(s, r, 0, s->mg_G))) return rc;     // (thin slabs: fewer exact div planes)
+    float rTr = 0.f, old_zTr = 0.f;
+    if ((rc = dot(r, r, &rTr))) return rc;                                             // :1237-1239
+    if ((rc = mg_precondition_slab(s))) return rc;                                     // :1244
+    fsk::cg_update_p(s->st, gw, p, z, 0.f);                                            // :1250
+    if ((rc = dot(z, r, &old_zTr))) return rc;                                         // :1252-1254
+    int it = 0;
+    for (; it < P.jacobi_iters; ++it) {
+        if ((rc = mg_exchange(s, p, 0, 1))) return rc;        // A p reaches one plane into the neighbours
+        fsk::cg_apply_a(s->st, gw, Ap, p);                                             // :1259
+        float pAp = 0.f;
+        if ((rc = dot(p, Ap, &pAp))) return rc;                                        // :1261
+        const float alpha = old_zTr / pAp;                                             // :1263
+        fsk::cg_update_xr(s->st, gw, x, r, p, Ap, alpha);                              // :1266
+        if ((rc = dot(r, r, &rTr))) return rc;                                         // :1269-1271
+        if (rTr < P.iter_precision || rTr == 0) {                                      // :1275
+            ++it;
+            break;
+        }
+        if ((rc = mg_exchange(s, r, 0, s->mg_G))) return rc;  // the V-cycle starts from exact ghost planes
+        if ((rc = mg_precondition_slab(s))) return rc;                                 // :1279
+        float new_zTr = 0.f;
+        if ((rc = dot(z, r, &new_zTr))) return rc;                                     // :1285-1287
+        const float beta = new_zTr / old_zTr;
+        fsk::cg_update_p(s->st, gw, p, z, beta);                                       // :1290
+        old_zTr = new_zTr;
+    }
+    s->last_sweeps = it;
+    s->cg_rtr = rTr;
+    // the pointer quirk of :1295, as in run_mgpcg
+    if (s->cg_x_is_pressure) fsk::cg_to_pressure(s->st, go, s->f.p, x + own);
+    s->cg_x_is_pressure = true;
+    s->prev_held = false;
+    s->p_ghost = 0;
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
 // sum r^2 over the whole grid (all ranks), binary64
 int residual_sync(fs_solver* s, bool previous, double* out)
 {
@@ -820,9 +994,12 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     if (p->pressure_solver != FS_PRESSURE_JACOBI && p->pressure_solver != FS_PRESSURE_MGPCG)
         return fail(FS_ERR_INVALID, "fs_create: unknown pressure_solver %d", p->pressure_solver);
     if (p->pressure_solver == FS_PRESSURE_MGPCG) {
-        if (world > 1) return fail(FS_ERR_INVALID, "fs_create_slab: FS_PRESSURE_MGPCG is single-GPU only");
         if (p->mg_level < 1 || p->mg_level > 8 || p->init_smooth_steps < 0 || p->bottom_smooth_steps < 0)
             return fail(FS_ERR_INVALID, "fs_create: bad multigrid parameters");
+        if (world > 1 && p->nz % (world << (p->mg_level - 1)) != 0)
+            return fail(FS_ERR_INVALID, "fs_create_slab: FS_PRESSURE_MGPCG needs nz to be a multiple of %d "
+                                        "(ranks x 2^(mg_level-1): every slab must coarsen on its own)",
+                        world << (p->mg_level - 1));
         const int m = 1 << (p->mg_level - 1);
         if (p->nx % m || p->ny % m || p->nz % m)
             return fail(FS_ERR_INVALID, "fs_create: FS_PRESSURE_MGPCG needs every dim to be a multiple of %d "
@@ -937,7 +1114,39 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             rc = fail(FS_ERR_HIP, "fs_create: hipMemset failed");
             break;
         }
-        if (p->pressure_solver == FS_PRESSURE_MGPCG) {
+        if (p->pressure_solver == FS_PRESSURE_MGPCG && world > 1) {
+            // windows of the levels: owned planes plus G ghost planes per non-wall side, G as deep
+            // as the coarsest level's slab allows (at most 4)
+            const int L = p->mg_level;
+            int G = g.nzl >> (L - 1);
+            if (G > 4) G = 4;
+            s->mg_G = G;
+            size_t off = 0;
+            for (int l = 0; l < L; ++l) {
+                fs_solver::MgWin W{};
+                W.nx = g.nx >> l; W.ny = g.ny >> l; W.nz = g.nz >> l;
+                W.z0 = g.z0 >> l; W.nzl = g.nzl >> l;
+                W.lo = g.wall_lo ? 0 : G; W.hi = g.wall_hi ? 0 : G;
+                W.off = off;
+                W.vz = 0;
+                off += (W.cell() * W.held() + 63) & ~(size_t)63;
+                s->mgw.push_back(W);
+            }
+            const size_t space_al = off, n = (s->mgw[0].cell() * s->mgw[0].held() + 63) & ~(size_t)63;
+            const size_t total = (2 * space_al + 3 * n) * sizeof(float);
+            e = hipMalloc((void**)&s->cg_r, total);
+            if (e != hipSuccess || hipMemsetAsync(s->cg_r, 0, total, s->st) != hipSuccess ||
+                hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 1) * sizeof(double)) != hipSuccess ||
+                hipHostMalloc((void**)&s->h_dot, sizeof(double)) != hipSuccess) {
+                rc = fail(FS_ERR_HIP, "fs_create_slab: MGPCG work arrays (%zu bytes)", total);
+                break;
+            }
+            s->cg_z = s->cg_r + space_al;
+            s->cg_p = s->cg_z + space_al;
+            s->cg_Ap = s->cg_p + n;
+            s->cg_x = s->cg_Ap + n;
+            s->cg_out = s->cg_partial + fsk::cg_dot_partials();
+        } else if (p->pressure_solver == FS_PRESSURE_MGPCG) {
             const size_t space = fsk::mg_space(g, p->mg_level), n = (size_t)g.nx * g.ny * g.nz;
             const size_t space_al = (space + 63) & ~(size_t)63;   // keeps every array 256-byte aligned
             const size_t total = (3 * space_al + 3 * n) * sizeof(float);
@@ -1385,7 +1594,7 @@ int fs_stage_project(fs_solver* s)
     int rc = fs_stage_divergence(s);
     if (rc) return rc;
     s->last_sweeps = 0;
-    if (s->prm.pressure_solver == FS_PRESSURE_MGPCG) return run_mgpcg(s);
+    if (s->prm.pressure_solver == FS_PRESSURE_MGPCG) return s->world > 1 ? run_mgpcg_slab(s) : run_mgpcg(s);
     if (s->prm.tolerance > 0.f) {
         // convergence mode: groups of check_every sweeps until sum r^2 < tolerance
         while (s->last_sweeps < s->prm.max_sweeps) {

@@ -99,7 +99,9 @@ typedef struct fs_params {
     int check_every;
     int max_sweeps;
     float curl_strength;         /* Solver.h:73   0.1, used with FS_FLAG_VORT_CONFINE */
-    /* FS_PRESSURE_MGPCG (single GPU; every dim a multiple of 2^(mg_level-1)): jacobi_iters is the
+    /* FS_PRESSURE_MGPCG (every dim a multiple of 2^(mg_level-1); on z-slabs nz a multiple of
+       ranks x 2^(mg_level-1), so that every slab coarsens on its own, and the dot products are sums
+       of the ranks' partial sums): jacobi_iters is the
        iteration limit, as max_iter is for both branches in the reference (Solver.cu:1256).  The
        solve follows the reference literally, including that the first solve after creation does
        not reach the pressure field (the swap at Solver.cu:1295 exchanges a by-value pointer). */
@@ -133,11 +135,12 @@ FS_API int fs_destroy(fs_solver* s);
       the reference, which is single-GPU).  Rank r owns cell planes [z0, z0 + nz_local) of the
       global grid p->nz is cut into; every other call below then acts on that slab and the
       host getters / fs_field_upload move the LOCAL planes only (nz_local planes, nz_local + 1
-      for FS_UZ).  Results are bit-identical to the single-GPU solver.
+      for FS_UZ).  Results are bit-identical to the single-GPU solver (with FS_PRESSURE_MGPCG: up
+      to the summation order of the dot products, which are reduced over the ranks).
       Transport, one of:
         * unique_id != NULL: RCCL.  Rank 0 obtains 128 bytes from fs_comm_unique_id and hands
           them to every rank (any out-of-band channel); halos travel as ncclSend/ncclRecv
-          between z-neighbours, the residual norm as ncclAllReduce.
+          between z-neighbours, the residual norm and MGPCG's dot products as ncclAllReduce.
         * unique_id == NULL, fn != NULL: host-staged.  The library packs halos into pinned
           host buffers and calls fn to move them (MPI, gloo, ...).  Used by the tests and as a
           fallback; fn(ctx, FS_XCHG_HALO, send_lo, recv_lo, send_hi, recv_hi, bytes) must
