@@ -122,13 +122,22 @@ size_t mg_space(const FsGrid& g, int levels);       // floats in r and in z (all
 int cg_dot_partials();                               // doubles the dot-product scratch must hold
 void cg_init(hipStream_t st, const FsGrid& g, float* r, float* x, const float* div);
 void cg_to_pressure(hipStream_t st, const FsGrid& g, float* p, const float* x);
+// A CG coefficient (alpha, beta): either a value the host has, or the quotient of two dot products
+// that are still on the device -- each narrowed to binary32 first, then divided in binary32, which is
+// what the reference's host code does with the numbers it has read back (Solver.cu:1263, 1288).
+struct CgScalar {
+    float v;
+    const double *num, *den;
+    CgScalar(float value) : v(value), num(nullptr), den(nullptr) {}
+    CgScalar(const double* n, const double* d) : v(0.f), num(n), den(d) {}
+};
 void cg_apply_a(hipStream_t st, const FsGrid& g, float* Ap, const float* p);
-void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap, float alpha);
-void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, float beta);
+void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap, CgScalar alpha);
+void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, CgScalar beta);
 void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, double* partial, double* out);
 void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, double* partial, double* out);
 void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap,
-                      float alpha, double* partial, double* out);
+                      CgScalar alpha, double* partial, double* out);
 float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, float* zalt, int levels,
                        int init_smooth_steps, int bottom_smooth_steps);   // returns z or zalt: the result
 // The same operations on a z-slab's windows of the levels (dense nx x ny x held arrays that hold the

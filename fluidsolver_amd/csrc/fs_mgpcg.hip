@@ -70,19 +70,28 @@ __global__ void k_apply_a(float* __restrict__ Ap, const float* __restrict__ p, D
     Ap[(size_t)i + (size_t)j * d.x + (size_t)k * d.x * d.y] = 6.f * pc - neibor_sum(p, i, j, k, d);
 }
 
+using fsk::CgScalar;
+
+__device__ __forceinline__ float cg_scalar(const CgScalar& c)
+{
+    return c.num ? (float)*c.num / (float)*c.den : c.v;
+}
+
 __global__ void k_update_xr(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ p,
-                            const float* __restrict__ Ap, float alpha, size_t n)
+                            const float* __restrict__ Ap, CgScalar coef, size_t n)
 {
     const size_t ind = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ind >= n) return;
+    const float alpha = cg_scalar(coef);
     x[ind] += alpha * p[ind];
     r[ind] -= alpha * Ap[ind];
 }
 
-__global__ void k_update_p(float* __restrict__ p, const float* __restrict__ z, float beta, size_t n)
+__global__ void k_update_p(float* __restrict__ p, const float* __restrict__ z, CgScalar coef, size_t n)
 {
     const size_t ind = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ind >= n) return;
+    const float beta = cg_scalar(coef);
     p[ind] = z[ind] + beta * p[ind];
 }
 
@@ -277,10 +286,11 @@ k_apply_a_dot4(float* __restrict__ Ap, const float* __restrict__ p, Dim3i d, dou
 // k_update_xr and the partial sums of the new r . r
 __global__ void __launch_bounds__(kDotBlock)
 k_update_xr_dot4(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ p,
-                 const float* __restrict__ Ap, float alpha, unsigned items, double* __restrict__ partial)
+                 const float* __restrict__ Ap, CgScalar coef, unsigned items, double* __restrict__ partial)
 {
     __shared__ double sh[kDotBlock / 64];
     double s = 0.0;
+    const float alpha = cg_scalar(coef);
     for (unsigned it = blockIdx.x * kDotBlock + threadIdx.x; it < items; it += gridDim.x * kDotBlock) {
         const size_t ind = (size_t)4 * it;
         const f4 pv = *(const f4*)(p + ind), av = *(const f4*)(Ap + ind);
@@ -399,7 +409,7 @@ void cg_apply_a(hipStream_t st, const FsGrid& g, float* Ap, const float* p)
     hipLaunchKernelGGL(k_apply_a, grid3(d), dim3(64, 4), 0, st, Ap, p, d);
 }
 
-void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap, float alpha)
+void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap, CgScalar alpha)
 {
     const size_t n = (size_t)g.nx * g.ny * g.nz;
     hipLaunchKernelGGL(k_update_xr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, r, p, Ap, alpha, n);
@@ -427,7 +437,7 @@ void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, 
 
 // x += alpha p, r -= alpha Ap and *out = r . r of the new r
 void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap,
-                      float alpha, double* partial, double* out)
+                      CgScalar alpha, double* partial, double* out)
 {
     const size_t n = (size_t)g.nx * g.ny * g.nz;
     if (n % 4 != 0) {
@@ -441,7 +451,7 @@ void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const
     hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
 }
 
-void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, float beta)
+void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, CgScalar beta)
 {
     const size_t n = (size_t)g.nx * g.ny * g.nz;
     hipLaunchKernelGGL(k_update_p, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, z, beta, n);

@@ -717,15 +717,6 @@ int run_jacobi(fs_solver* s, int sweeps)
 
 // ---- MGPCG -------------------------------------------------------------------------------------
 
-// dot product as the float the reference's host logic reads (synchronises)
-int cg_read_sum(fs_solver* s, float* out);
-
-int cg_dot_sync(fs_solver* s, const float* a, const float* b, float* out)
-{
-    fsk::cg_dot(s->st, s->g, a, b, s->cg_partial, s->cg_out);
-    return cg_read_sum(s, out);
-}
-
 // the sum a fused kernel pair has left in cg_out, as the float the host logic reads (synchronises)
 int cg_read_sum(fs_solver* s, float* out)
 {
@@ -751,30 +742,34 @@ int run_mgpcg(fs_solver* s)
         }
     };
     int rc;
+    // The dot products stay on the device: alpha and beta are formed by the kernels that use them
+    // (CgScalar), and the host reads back only r.r, the one number its control flow depends on.
+    double *d_rtr = s->cg_out, *d_pap = s->cg_out + 1, *d_zo = s->cg_out + 2, *d_zn = s->cg_out + 3;
     fsk::cg_init(s->st, g, r, x, s->f.div);                       // :1233
-    float rTr = 0.f, old_zTr = 0.f;
-    if ((rc = cg_dot_sync(s, r, r, &rTr))) return rc;             // init_rTr :1237-1239
+    float rTr = 0.f;
+    if (P.jacobi_iters <= 0) {
+        // init_rTr :1237-1239 is only printed by the reference; here it is the reported r.r of a
+        // solve that is not allowed a single iteration
+        fsk::cg_dot(s->st, g, r, r, s->cg_partial, d_rtr);
+        if ((rc = cg_read_sum(s, &rTr))) return rc;
+    }
     precondition();                                               // :1244
     fsk::cg_update_p(s->st, g, p, z, 0.f);                        // :1250
-    if ((rc = cg_dot_sync(s, z, r, &old_zTr))) return rc;         // :1252-1254
+    fsk::cg_dot(s->st, g, z, r, s->cg_partial, d_zo);             // old_zTr :1252-1254
     int it = 0;
     for (; it < P.jacobi_iters; ++it) {
-        fsk::cg_apply_a_dot(s->st, g, Ap, p, s->cg_partial, s->cg_out);   // :1259 and the products of :1261
-        float pAp = 0.f;
-        if ((rc = cg_read_sum(s, &pAp))) return rc;
-        const float alpha = old_zTr / pAp;                        // :1263
-        fsk::cg_update_xr_dot(s->st, g, x, r, p, Ap, alpha, s->cg_partial, s->cg_out);   // :1266, :1269-1271
+        fsk::cg_apply_a_dot(s->st, g, Ap, p, s->cg_partial, d_pap);   // :1259 and the products of :1261
+        // alpha = old_zTr / pAp :1263, then :1266 and :1269-1271
+        fsk::cg_update_xr_dot(s->st, g, x, r, p, Ap, fsk::CgScalar(d_zo, d_pap), s->cg_partial, d_rtr);
         if ((rc = cg_read_sum(s, &rTr))) return rc;
         if (rTr < P.iter_precision || rTr == 0) {                 // :1275
             ++it;
             break;
         }
         precondition();                                           // :1279
-        float new_zTr = 0.f;
-        if ((rc = cg_dot_sync(s, z, r, &new_zTr))) return rc;     // :1285-1287
-        const float beta = new_zTr / old_zTr;
-        fsk::cg_update_p(s->st, g, p, z, beta);                   // :1290
-        old_zTr = new_zTr;
+        fsk::cg_dot(s->st, g, z, r, s->cg_partial, d_zn);         // new_zTr :1285-1287
+        fsk::cg_update_p(s->st, g, p, z, fsk::CgScalar(d_zn, d_zo));   // beta = new_zTr / old_zTr :1288-1290
+        std::swap(d_zo, d_zn);
     }
     s->last_sweeps = it;
     s->cg_rtr = rTr;
@@ -797,21 +792,25 @@ int run_mgpcg(fs_solver* s)
 // before an owned plane could be touched.  The count follows the same rule on every rank (walls
 // are not special-cased), so all ranks make the same sequence of exchanges.
 
-// the sum over all ranks of the double a kernel pair has left in cg_out, narrowed to the float the
-// reference's host logic works with (synchronises)
-int cg_read_sum_all(fs_solver* s, float* out)
+// *slot (a device double a kernel pair has just written) becomes its sum over all ranks, on the
+// device; with `out` the host also gets it, narrowed to the float the reference's host logic works
+// with (synchronises).  The host-staged transport sums on the host in any case.
+int cg_sum_all(fs_solver* s, double* slot, float* out)
 {
     if (s->comm) {
         Rccl* R = rccl();
-        FS_NCCL(R->AllReduce(s->cg_out, s->cg_out, 1, ncclDouble, ncclSum, s->comm, s->st));
+        FS_NCCL(R->AllReduce(slot, slot, 1, ncclDouble, ncclSum, s->comm, s->st));
+        if (!out) return FS_OK;
     }
-    FS_HIP(hipMemcpyAsync(s->h_dot, s->cg_out, sizeof(double), hipMemcpyDeviceToHost, s->st));
+    FS_HIP(hipMemcpyAsync(s->h_dot, slot, sizeof(double), hipMemcpyDeviceToHost, s->st));
     FS_HIP(hipStreamSynchronize(s->st));
     if (!s->comm) {
         int rc = s->xfn(s->xctx, FS_XCHG_SUM_F64, s->h_dot, nullptr, nullptr, nullptr, sizeof(double));
         if (rc) return fail(FS_ERR_COMM, "rank %d: the all-reduce callback returned %d", s->rank, rc);
+        // (the copy reads h_dot in stream order before the next read-back overwrites it)
+        FS_HIP(hipMemcpyAsync(slot, s->h_dot, sizeof(double), hipMemcpyHostToDevice, s->st));
     }
-    *out = (float)*s->h_dot;
+    if (out) *out = (float)*s->h_dot;
     return FS_OK;
 }
 
@@ -905,39 +904,37 @@ int run_mgpcg_slab(fs_solver* s)
     FsGrid gw = g, go = g;
     gw.nz = W.held();
     go.nz = W.nzl;
-    auto dot = [&](const float* a, const float* b, float* out) {
-        fsk::cg_dot(s->st, go, a + own, b + own, s->cg_partial, s->cg_out);
-        return cg_read_sum_all(s, out);
+    // the dot products stay on the device, as in run_mgpcg; the host reads r.r only
+    double *d_rtr = s->cg_out, *d_pap = s->cg_out + 1, *d_zo = s->cg_out + 2, *d_zn = s->cg_out + 3;
+    auto dot = [&](const float* a, const float* b, double* slot, float* out) {
+        fsk::cg_dot(s->st, go, a + own, b + own, s->cg_partial, slot);
+        return cg_sum_all(s, slot, out);
     };
     int rc = FS_OK;
     // r = -div on every held plane (the divergence is exact pghost - 1 planes beyond the slab), x = 0
     fsk::cg_init(s->st, gw, r, x, s->f.div - (ptrdiff_t)W.lo * g.plane);               // :1233
     if (g.pghost - 1 < s->mg_G && (rc = mg_exchange(s, r, 0, s->mg_G))) return rc;     // (thin slabs: fewer exact div planes)
-    float rTr = 0.f, old_zTr = 0.f;
-    if ((rc = dot(r, r, &rTr))) return rc;                                             // :1237-1239
+    float rTr = 0.f;
+    if (P.jacobi_iters <= 0 && (rc = dot(r, r, d_rtr, &rTr))) return rc;               // :1237-1239
     if ((rc = mg_precondition_slab(s))) return rc;                                     // :1244
     fsk::cg_update_p(s->st, gw, p, z, 0.f);                                            // :1250
-    if ((rc = dot(z, r, &old_zTr))) return rc;                                         // :1252-1254
+    if ((rc = dot(z, r, d_zo, nullptr))) return rc;                                    // :1252-1254
     int it = 0;
     for (; it < P.jacobi_iters; ++it) {
         if ((rc = mg_exchange(s, p, 0, 1))) return rc;        // A p reaches one plane into the neighbours
         fsk::cg_apply_a(s->st, gw, Ap, p);                                             // :1259
-        float pAp = 0.f;
-        if ((rc = dot(p, Ap, &pAp))) return rc;                                        // :1261
-        const float alpha = old_zTr / pAp;                                             // :1263
-        fsk::cg_update_xr(s->st, gw, x, r, p, Ap, alpha);                              // :1266
-        if ((rc = dot(r, r, &rTr))) return rc;                                         // :1269-1271
+        if ((rc = dot(p, Ap, d_pap, nullptr))) return rc;                              // :1261
+        fsk::cg_update_xr(s->st, gw, x, r, p, Ap, fsk::CgScalar(d_zo, d_pap));         // :1263, :1266
+        if ((rc = dot(r, r, d_rtr, &rTr))) return rc;                                  // :1269-1271
         if (rTr < P.iter_precision || rTr == 0) {                                      // :1275
             ++it;
             break;
         }
         if ((rc = mg_exchange(s, r, 0, s->mg_G))) return rc;  // the V-cycle starts from exact ghost planes
         if ((rc = mg_precondition_slab(s))) return rc;                                 // :1279
-        float new_zTr = 0.f;
-        if ((rc = dot(z, r, &new_zTr))) return rc;                                     // :1285-1287
-        const float beta = new_zTr / old_zTr;
-        fsk::cg_update_p(s->st, gw, p, z, beta);                                       // :1290
-        old_zTr = new_zTr;
+        if ((rc = dot(z, r, d_zn, nullptr))) return rc;                                // :1285-1287
+        fsk::cg_update_p(s->st, gw, p, z, fsk::CgScalar(d_zn, d_zo));                  // :1288-1290
+        std::swap(d_zo, d_zn);
     }
     s->last_sweeps = it;
     s->cg_rtr = rTr;
@@ -1136,7 +1133,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             const size_t total = (2 * space_al + 3 * n) * sizeof(float);
             e = hipMalloc((void**)&s->cg_r, total);
             if (e != hipSuccess || hipMemsetAsync(s->cg_r, 0, total, s->st) != hipSuccess ||
-                hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 1) * sizeof(double)) != hipSuccess ||
+                hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 4) * sizeof(double)) != hipSuccess ||
                 hipHostMalloc((void**)&s->h_dot, sizeof(double)) != hipSuccess) {
                 rc = fail(FS_ERR_HIP, "fs_create_slab: MGPCG work arrays (%zu bytes)", total);
                 break;
@@ -1152,7 +1149,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             const size_t total = (3 * space_al + 3 * n) * sizeof(float);
             e = hipMalloc((void**)&s->cg_r, total);
             if (e != hipSuccess || hipMemsetAsync(s->cg_r, 0, total, s->st) != hipSuccess ||
-                hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 1) * sizeof(double)) != hipSuccess ||
+                hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 4) * sizeof(double)) != hipSuccess ||
                 hipHostMalloc((void**)&s->h_dot, sizeof(double)) != hipSuccess) {
                 rc = fail(FS_ERR_HIP, "fs_create: MGPCG work arrays (%zu bytes)", total);
                 break;
