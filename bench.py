@@ -96,9 +96,10 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fluidsolver_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        # the kernel files; the host-side orchestration (fs_solver.hip) does not change what a
-        # launch moves
-        if name.endswith((".hip", ".h")) and name != "fs_solver.hip":
+        # the files of the kernels this benchmark launches; the host-side orchestration
+        # (fs_solver.hip) does not change what a launch moves, and the optional stages' kernels
+        # (fs_mgpcg.hip, fs_vort.hip) are not launched by it
+        if name.endswith((".hip", ".h")) and name not in ("fs_solver.hip", "fs_mgpcg.hip", "fs_vort.hip"):
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
