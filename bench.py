@@ -179,6 +179,48 @@ def launch_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+ABANDONED = []   # solvers whose transport failed: kept alive, never destroyed (see main)
+
+
+def open_slab_solver(make, p, rank, world, want, warmup, all_min):
+    """(solver, transport, warm-up steps left) for one rank of a z-slab run.  `make(p, rank, world,
+    transport=...)` builds a solver, `all_min(int)` is the minimum over the ranks.  RCCL is tried
+    first when asked for; every rank must end up on the same transport, so each decision is taken
+    on the minimum over all ranks of "it worked here"."""
+    solver, transport = None, want
+    if transport == "rccl":
+        ok = 1
+        try:
+            solver = make(p, rank, world, transport="rccl").Initialize()
+        except Exception as e:   # noqa: BLE001
+            print("bench.py rank %d: RCCL transport unavailable (%s)" % (rank, e), file=sys.stderr)
+            ok = 0
+        if all_min(ok) == 0:
+            if solver is not None:
+                solver.close()
+            solver, transport = None, "host"
+    if solver is not None and transport == "rccl" and warmup > 0:
+        # the first warm-up step doubles as a trial of the transport: a transfer that does not
+        # complete is reported by the library after FS_XCHG_TIMEOUT_MS instead of hanging, and
+        # then every rank goes on with host-staged halos, so that the run still yields a number
+        ok = 1
+        try:
+            solver.step(1)
+            solver.sync()
+        except Exception as e:   # noqa: BLE001
+            print("bench.py rank %d: RCCL transport failed in the first step (%s)" % (rank, e), file=sys.stderr)
+            ok = 0
+        if all_min(ok) == 0:
+            # not closed: destroying a communicator with a transfer stuck in it may block
+            ABANDONED.append(solver)
+            solver, transport = None, "host"
+        else:
+            warmup -= 1
+    if solver is None:
+        solver = make(p, rank, world, transport="host").Initialize()
+    return solver, transport, warmup
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +284,7 @@ def main():
     conv = {}
     if args.tolerance > 0:
         conv = dict(tolerance=args.tolerance, check_every=args.check_every, max_sweeps=args.iters)
+    warm_left = args.warmup
     if world == 1:
         p = fs.default_params(n, n, n, jacobi_iters=args.iters, scheme=args.scheme,
                               device=device, flags=flags, **conv)
@@ -253,25 +296,13 @@ def main():
         from fluidsolver_amd.slab import SlabSolver
         p = fs.default_params(n, n, nz_total, jacobi_iters=args.iters, scheme=args.scheme,
                               device=device, flags=flags, **conv)
-        transport = args.transport
-        solver = None
-        if transport == "rccl":
-            ok = 1
-            try:
-                solver = SlabSolver(p, rank, world, transport="rccl").Initialize()
-            except Exception as e:   # noqa: BLE001
-                print("bench.py rank %d: RCCL transport unavailable (%s)" % (rank, e), file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok])
+
+        def all_min(v):
+            flag = torch.tensor([v])
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                # every rank must use the same transport: all fall back to host-staged halos
-                if solver is not None:
-                    solver.close()
-                solver = None
-                transport = "host"
-        if solver is None:
-            solver = SlabSolver(p, rank, world, transport="host").Initialize()
+            return int(flag.item())
+
+        solver, transport, warm_left = open_slab_solver(SlabSolver, p, rank, world, args.transport, args.warmup, all_min)
         cells_total = n * n * nz_total
         workload = ("%dx%dx%d %s, %d Jacobi sweeps/step, MacCormack, z-slabs on %d GPUs, "
                     "halos over %s" % (n, n, nz_total,
@@ -286,7 +317,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    solver.step(args.warmup)
+    solver.step(warm_left)
     barrier()
     solver.profile(True)
     solver.profile_reset()
@@ -394,6 +425,11 @@ def main():
     solver.close()
     if dist is not None:
         dist.destroy_process_group()
+    if ABANDONED:
+        # leave without running the destructors of a solver whose transfers never completed
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -48,3 +50,55 @@ def test_counter_summary_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     assert bench.load_pmc("jacobi", "256^3") == (None, False)
     (prof / "pmc_traffic.json").write_text(json.dumps({"source_hash": "other", "kernels": {"jacobi": {"512^3": entry}}}))
     assert bench.load_pmc("jacobi", "512^3") == (entry, True)
+
+
+class _FakeSolver:
+    """Stand-in for SlabSolver: `plan` says which transports fail to initialise or to step."""
+    plan = {}
+    made = []
+
+    def __init__(self, p, rank, world, transport):
+        self.transport, self.steps, self.closed = transport, 0, False
+        _FakeSolver.made.append(self)
+
+    def Initialize(self):
+        if _FakeSolver.plan.get(self.transport) == "init":
+            raise RuntimeError("no such transport here")
+        return self
+
+    def step(self, n=1):
+        if _FakeSolver.plan.get(self.transport) == "step":
+            raise RuntimeError("the transfer did not finish")
+        self.steps += n
+
+    def sync(self):
+        pass
+
+    def close(self):
+        self.closed = True
+
+
+@pytest.mark.parametrize("plan,want,transport,warm_left,abandoned", [
+    ({}, "rccl", "rccl", 2, 0),                       # the trial step is the first warm-up step
+    ({"rccl": "init"}, "rccl", "host", 3, 0),         # RCCL cannot be set up: host-staged halos
+    ({"rccl": "step"}, "rccl", "host", 3, 1),         # a transfer times out: abandoned, never closed
+    ({}, "host", "host", 3, 0),
+])
+def test_bench_transport_selection(plan, want, transport, warm_left, abandoned, monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "ABANDONED", [])
+    _FakeSolver.plan, _FakeSolver.made = plan, []
+    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, want, 3, lambda v: v)
+    assert (t, w, len(bench.ABANDONED)) == (transport, warm_left, abandoned)
+    assert s.transport == transport and not s.closed
+    for other in _FakeSolver.made:
+        assert other is s or not other.closed      # failed to initialise, or abandoned: never closed
+    # RCCL fine here but not on another rank: this rank's RCCL solver is closed, all use the host transport
+    _FakeSolver.plan, _FakeSolver.made = {}, []
+    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, "rccl", 3, lambda v: 0)
+    if want == "rccl":
+        assert t == "host" and _FakeSolver.made[0].closed and s is _FakeSolver.made[1]
+    # without warm-up steps there is no trial
+    _FakeSolver.plan, _FakeSolver.made = {"rccl": "step"}, []
+    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, "rccl", 0, lambda v: v)
+    assert (t, w) == ("rccl", 0)
