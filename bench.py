@@ -253,6 +253,13 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    # gloo and RCCL announce themselves on stdout (connections, a version banner); the one JSON
+    # line must stay alone there, so everything else this process and its libraries print goes to
+    # stderr and the line is written to the original stdout at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import fluidsolver_amd as fs
 
@@ -267,16 +274,7 @@ def main():
         # torch.distributed is the control plane only (unique-id hand-out, barriers, max over
         # ranks); the halos travel inside the library over RCCL
         import torch.distributed as dist
-        # gloo announces its connections on stdout; the one JSON line must stay alone there
-        sys.stdout.flush()
-        keep = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        finally:
-            sys.stdout.flush()
-            os.dup2(keep, 1)
-            os.close(keep)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n = args.size
     nz_total = n * world if args.scaling == "weak" else n
@@ -420,7 +418,8 @@ def main():
             out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_sample)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     solver.close()
     if dist is not None:
