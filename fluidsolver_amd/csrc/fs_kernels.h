@@ -135,9 +135,12 @@ void cg_apply_a(hipStream_t st, const FsGrid& g, float* Ap, const float* p);
 void cg_update_xr(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap, CgScalar alpha);
 void cg_update_p(hipStream_t st, const FsGrid& g, float* p, const float* z, CgScalar beta);
 void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, double* partial, double* out);
-void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, double* partial, double* out);
+// (k_lo, k_hi: the planes of g whose products enter the sum -- a slab's own planes inside its window;
+//  the operator and the update cover all of g either way; k_hi < 0 = all planes)
+void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, double* partial, double* out,
+                    int k_lo = 0, int k_hi = -1);
 void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap,
-                      CgScalar alpha, double* partial, double* out);
+                      CgScalar alpha, double* partial, double* out, int k_lo = 0, int k_hi = -1);
 float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, float* zalt, int levels,
                        int init_smooth_steps, int bottom_smooth_steps);   // returns z or zalt: the result
 // The same operations on a z-slab's windows of the levels (dense nx x ny x held arrays that hold the
@@ -146,6 +149,8 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
 // window plane of the lower children of the first of them), prolongation over every fine plane whose
 // parent the coarse window holds (f0 / c0 = global index of the fine / coarse window's plane 0).
 void mgs_smooth_phase(hipStream_t st, const float* r, float* z, int nx, int ny, int held, int phase, int kpar);
+bool mgs_smooth_pass(hipStream_t st, const float* r, const float* z, float* zalt, int nx, int ny, int held, int colours,
+                     bool z_is_zero);
 void mgs_restrict(hipStream_t st, const float* rf, const float* zf, int nx, int ny, int held_f, int fk0,
                   float* rc_owned, int cz);
 void mgs_prolongate(hipStream_t st, float* zf, int nx, int ny, int held_f, int f0, const float* zc, int c0, int cheld);

@@ -253,7 +253,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // k_apply_a and the partial sums of p . Ap in one pass over p; four cells along x per thread
 // (nx % 4 == 0), a fixed strided set of quads per thread.
 __global__ void __launch_bounds__(kDotBlock)
-k_apply_a_dot4(float* __restrict__ Ap, const float* __restrict__ p, Dim3i d, double* __restrict__ partial)
+k_apply_a_dot4(float* __restrict__ Ap, const float* __restrict__ p, Dim3i d, double* __restrict__ partial, int k_lo,
+               int k_hi)
 {
     __shared__ double sh[kDotBlock / 64];
     const unsigned nx4 = (unsigned)d.x >> 2, items = nx4 * (unsigned)d.y * (unsigned)d.z;
@@ -274,6 +275,7 @@ k_apply_a_dot4(float* __restrict__ Ap, const float* __restrict__ p, Dim3i d, dou
         a.z = 6.f * c.z - (c.y + c.w + dn.z + up.z + bk.z + fw.z);
         a.w = 6.f * c.w - (c.z + rgt + dn.w + up.w + bk.w + fw.w);
         *(f4*)(Ap + ind) = a;
+        if (k < k_lo || k >= k_hi) continue;   // (a slab's window: only its own planes count)
         s += (double)(c.x * a.x);
         s += (double)(c.y * a.y);
         s += (double)(c.z * a.z);
@@ -286,7 +288,8 @@ k_apply_a_dot4(float* __restrict__ Ap, const float* __restrict__ p, Dim3i d, dou
 // k_update_xr and the partial sums of the new r . r
 __global__ void __launch_bounds__(kDotBlock)
 k_update_xr_dot4(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ p,
-                 const float* __restrict__ Ap, CgScalar coef, unsigned items, double* __restrict__ partial)
+                 const float* __restrict__ Ap, CgScalar coef, unsigned items, double* __restrict__ partial,
+                 unsigned it_lo, unsigned it_hi)
 {
     __shared__ double sh[kDotBlock / 64];
     double s = 0.0;
@@ -299,6 +302,7 @@ k_update_xr_dot4(float* __restrict__ x, float* __restrict__ r, const float* __re
         rv -= alpha * av;
         *(f4*)(x + ind) = xv;
         *(f4*)(r + ind) = rv;
+        if (it < it_lo || it >= it_hi) continue;
         s += (double)(rv.x * rv.x);
         s += (double)(rv.y * rv.y);
         s += (double)(rv.z * rv.z);
@@ -422,32 +426,40 @@ static int dot_blocks(size_t work)
 }
 
 // Ap = A p and *out = p . Ap
-void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, double* partial, double* out)
+void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, double* partial, double* out, int k_lo,
+                    int k_hi)
 {
+    if (k_hi < 0) k_hi = g.nz;
     if (g.nx % 4 != 0) {
         cg_apply_a(st, g, Ap, p);
-        cg_dot(st, g, p, Ap, partial, out);
+        FsGrid go = g;
+        go.nz = k_hi - k_lo;
+        const size_t o = (size_t)k_lo * g.nx * g.ny;
+        cg_dot(st, go, p + o, Ap + o, partial, out);
         return;
     }
     const Dim3i d{g.nx, g.ny, g.nz};
     const int blocks = dot_blocks((size_t)g.nx / 4 * g.ny * g.nz);
-    hipLaunchKernelGGL(k_apply_a_dot4, dim3(blocks), dim3(kDotBlock), 0, st, Ap, p, d, partial);
+    hipLaunchKernelGGL(k_apply_a_dot4, dim3(blocks), dim3(kDotBlock), 0, st, Ap, p, d, partial, k_lo, k_hi);
     hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
 }
 
 // x += alpha p, r -= alpha Ap and *out = r . r of the new r
 void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap,
-                      CgScalar alpha, double* partial, double* out)
+                      CgScalar alpha, double* partial, double* out, int k_lo, int k_hi)
 {
-    const size_t n = (size_t)g.nx * g.ny * g.nz;
-    if (n % 4 != 0) {
+    if (k_hi < 0) k_hi = g.nz;
+    const size_t n = (size_t)g.nx * g.ny * g.nz, cell = (size_t)g.nx * g.ny;
+    if (n % 4 != 0 || cell % 4 != 0) {
         cg_update_xr(st, g, x, r, p, Ap, alpha);
-        cg_dot(st, g, r, r, partial, out);
+        FsGrid go = g;
+        go.nz = k_hi - k_lo;
+        cg_dot(st, go, r + k_lo * cell, r + k_lo * cell, partial, out);
         return;
     }
     const int blocks = dot_blocks(n / 4);
     hipLaunchKernelGGL(k_update_xr_dot4, dim3(blocks), dim3(kDotBlock), 0, st, x, r, p, Ap, alpha, (unsigned)(n / 4),
-                       partial);
+                       partial, (unsigned)(k_lo * cell / 4), (unsigned)(k_hi * cell / 4));
     hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
 }
 
@@ -551,6 +563,15 @@ void mgs_smooth_phase(hipStream_t st, const float* r, float* z, int nx, int ny, 
     const Dim3i d{nx, ny, held};
     hipLaunchKernelGGL(k_smooth, dim3(cdiv(cdiv(nx, 2), 32), cdiv(ny, 4), held), dim3(32, 4), 0, st, r, z, phase & 1, d,
                        kpar & 1);
+}
+
+// `colours` (2 or 4, red first) colours of the window in one blocked pass from z into zalt; false if
+// the level is not one the blocked kernel is used for (nothing launched)
+bool mgs_smooth_pass(hipStream_t st, const float* r, const float* z, float* zalt, int nx, int ny, int held, int colours,
+                     bool z_is_zero)
+{
+    if ((long)nx * ny < mg_tb_min_plane()) return false;
+    return rbgs_pass(st, nx, ny, held, r, z, zalt, colours, z_is_zero);
 }
 
 void mgs_restrict(hipStream_t st, const float* rf, const float* zf, int nx, int ny, int held_f, int fk0,

@@ -139,19 +139,19 @@ struct fs_solver {
     float *cg_r = nullptr, *cg_z = nullptr, *cg_zalt = nullptr, *cg_p = nullptr, *cg_Ap = nullptr, *cg_x = nullptr;
     double *cg_partial = nullptr, *cg_out = nullptr;
     double* h_dot = nullptr;          // pinned
-    // MGPCG on a z-slab: this rank's window of every level (owned planes plus mg_G ghost planes per
+    // MGPCG on a z-slab: this rank's window of every level (owned planes plus G ghost planes per
     // non-wall side) inside the dense work arrays; vz = ghost planes of z that are exact right now
     struct MgWin {
         int nx, ny, nz;    // global dims of the level
         int z0, nzl;       // owned planes
-        int lo, hi;        // ghost planes held below / above
+        int G;             // ghost depth of the level (the same on every rank)
+        int lo, hi;        // ghost planes held below / above: G, or 0 at a wall
         size_t off;        // offset of the window inside r and z
         int vz;
         size_t cell() const { return (size_t)nx * ny; }
         int held() const { return lo + nzl + hi; }
     };
     std::vector<MgWin> mgw;
-    int mg_G = 0;
     bool cg_x_is_pressure = false;    // the reference's member x has become the pressure buffer
     float cg_rtr = 0.f;
     size_t field_elems = 0;           // floats per field including slack and ghost planes
@@ -826,36 +826,56 @@ int mg_exchange(fs_solver* s, float* base, int l, int planes)
     g.recv_lo = W.lo ? own - (size_t)planes * c : nullptr;
     g.send_hi = W.hi ? own + (size_t)(W.nzl - planes) * c : nullptr;
     g.recv_hi = W.hi ? own + (size_t)W.nzl * c : nullptr;
-    return exchange(s, &g, 1);
+    // nothing runs beside these transfers (the next launch needs them), so they go on the compute
+    // stream itself: no event hand-overs between two queues for a message of a few planes
+    const int keep = s->xchg_streams;
+    s->xchg_streams = 0;
+    const int rc = exchange(s, &g, 1);
+    s->xchg_streams = keep;
+    return rc;
 }
 
-// `steps` red/black sweeps of level l (Smooth, Solver.cu:848-860), one launch per colour
-int mg_smooth_slab(fs_solver* s, int l, int steps, bool from_zero)
+// `steps` red/black sweeps of level l (Smooth, Solver.cu:848-860) on the window whose current
+// iterate is in z.  Levels with large planes take four (or two) colours per launch through the
+// temporally blocked kernel, from z into zalt (the two are swapped on return); the others one launch
+// per colour in place.  Either way a launch of c colours uses up c exact ghost planes.
+int mg_smooth_slab(fs_solver* s, int l, int steps, bool from_zero, float*& z, float*& zalt)
 {
     fs_solver::MgWin& W = s->mgw[l];
-    float *r = s->cg_r + W.off, *z = s->cg_z + W.off;
-    const int G = s->mg_G, kpar = (W.z0 - W.lo) & 1;
-    for (int ph = 0; ph < 2 * steps; ++ph) {
-        if (from_zero && ph == 0) {
-            W.vz = G;   // z = 0 is exact everywhere, and so is the first colour computed from it
-        } else {
-            if (W.vz < 1) {
-                int rc = mg_exchange(s, z, l, G);
-                if (rc) return rc;
-                W.vz = G;
-            }
-            W.vz -= 1;
+    float* r = s->cg_r + W.off;
+    const int kpar = (W.z0 - W.lo) & 1, phases = 2 * steps;
+    // (the blocked kernel takes the colour of a cell from the window's own plane numbers)
+    bool blocked = kpar == 0 && W.G >= 2;
+    for (int ph = 0; ph < phases;) {
+        int take = 1;
+        if (blocked) take = (phases - ph >= 4 && W.G >= 4) ? 4 : 2;
+        const bool zero_in = from_zero && ph == 0;
+        if (zero_in) {
+            W.vz = W.G + 1;   // z = 0 is exact everywhere, and so is the first colour computed from it
+        } else if (W.vz < take) {
+            int rc = mg_exchange(s, z, l, W.G);
+            if (rc) return rc;
+            W.vz = W.G;
         }
-        fsk::mgs_smooth_phase(s->st, r, z, W.nx, W.ny, W.held(), ph, kpar);
+        if (blocked && fsk::mgs_smooth_pass(s->st, r, z, zalt, W.nx, W.ny, W.held(), take, zero_in)) {
+            std::swap(z, zalt);
+        } else {
+            blocked = false;
+            take = 1;
+            fsk::mgs_smooth_phase(s->st, r, z, W.nx, W.ny, W.held(), ph, kpar);
+        }
+        W.vz -= take;
+        ph += take;
     }
     return FS_OK;
 }
 
-// one V-cycle (MG_Preconditioner, Solver.cu:1312-1366): level 0 of r (ghost planes exact) -> level 0 of z
+// one V-cycle (MG_Preconditioner, Solver.cu:1312-1366): level 0 of r (ghost planes exact) -> level 0
+// of z (s->cg_z on return; the blocked passes alternate between cg_z and cg_zalt)
 int mg_precondition_slab(fs_solver* s)
 {
     const fs_params& P = s->prm;
-    const int L = P.mg_level, G = s->mg_G;
+    const int L = P.mg_level;
     // z of every level and the coarse levels of r start at zero
     {
         const fs_solver::MgWin& W0 = s->mgw[0];
@@ -863,29 +883,34 @@ int mg_precondition_slab(fs_solver* s)
         FS_HIP(hipMemsetAsync(s->cg_z, 0, space * sizeof(float), s->st));
         if (space > n0) FS_HIP(hipMemsetAsync(s->cg_r + n0, 0, (space - n0) * sizeof(float), s->st));
     }
+    float *z[16], *za[16];
+    for (int l = 0; l < L; ++l) {
+        z[l] = s->cg_z + s->mgw[l].off;
+        za[l] = s->cg_zalt + s->mgw[l].off;
+    }
     int rc;
     for (int l = 0; l < L - 1; ++l) {
         fs_solver::MgWin &W = s->mgw[l], &C = s->mgw[l + 1];
-        if ((rc = mg_smooth_slab(s, l, P.init_smooth_steps << l, true))) return rc;
+        if ((rc = mg_smooth_slab(s, l, P.init_smooth_steps << l, true, z[l], za[l]))) return rc;
         // the residual of a child needs z one plane beyond it
         if (W.vz < 1) {
-            if ((rc = mg_exchange(s, s->cg_z + W.off, l, G))) return rc;
-            W.vz = G;
+            if ((rc = mg_exchange(s, z[l], l, W.G))) return rc;
+            W.vz = W.G;
         }
-        fsk::mgs_restrict(s->st, s->cg_r + W.off, s->cg_z + W.off, W.nx, W.ny, W.held(), W.lo,
+        fsk::mgs_restrict(s->st, s->cg_r + W.off, z[l], W.nx, W.ny, W.held(), W.lo,
                           s->cg_r + C.off + (size_t)C.lo * C.cell(), C.nzl);
         // the coarse right-hand side of the ghost planes comes from the ranks that own them
-        if ((rc = mg_exchange(s, s->cg_r + C.off, l + 1, G))) return rc;
+        if ((rc = mg_exchange(s, s->cg_r + C.off, l + 1, C.G))) return rc;
     }
-    if ((rc = mg_smooth_slab(s, L - 1, P.bottom_smooth_steps, true))) return rc;
+    if ((rc = mg_smooth_slab(s, L - 1, P.bottom_smooth_steps, true, z[L - 1], za[L - 1]))) return rc;
     for (int l = L - 2; l >= 0; --l) {
         fs_solver::MgWin &W = s->mgw[l], &C = s->mgw[l + 1];
-        fsk::mgs_prolongate(s->st, s->cg_z + W.off, W.nx, W.ny, W.held(), W.z0 - W.lo, s->cg_z + C.off, C.z0 - C.lo,
-                            C.held());
+        fsk::mgs_prolongate(s->st, z[l], W.nx, W.ny, W.held(), W.z0 - W.lo, z[l + 1], C.z0 - C.lo, C.held());
         // a fine ghost plane d planes out has its parent ceil(d/2) planes out
         W.vz = W.vz < 2 * C.vz ? W.vz : 2 * C.vz;
-        if ((rc = mg_smooth_slab(s, l, P.init_smooth_steps << l, false))) return rc;
+        if ((rc = mg_smooth_slab(s, l, P.init_smooth_steps << l, false, z[l], za[l]))) return rc;
     }
+    if (z[0] != s->cg_z) std::swap(s->cg_z, s->cg_zalt);
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -913,25 +938,30 @@ int run_mgpcg_slab(fs_solver* s)
     int rc = FS_OK;
     // r = -div on every held plane (the divergence is exact pghost - 1 planes beyond the slab), x = 0
     fsk::cg_init(s->st, gw, r, x, s->f.div - (ptrdiff_t)W.lo * g.plane);               // :1233
-    if (g.pghost - 1 < s->mg_G && (rc = mg_exchange(s, r, 0, s->mg_G))) return rc;     // (thin slabs: fewer exact div planes)
+    if (g.pghost - 1 < W.G && (rc = mg_exchange(s, r, 0, W.G))) return rc;             // (thin slabs: fewer exact div planes)
     float rTr = 0.f;
     if (P.jacobi_iters <= 0 && (rc = dot(r, r, d_rtr, &rTr))) return rc;               // :1237-1239
     if ((rc = mg_precondition_slab(s))) return rc;                                     // :1244
+    z = s->cg_z;   // (the V-cycle leaves its result in either z buffer and makes that one cg_z)
     fsk::cg_update_p(s->st, gw, p, z, 0.f);                                            // :1250
     if ((rc = dot(z, r, d_zo, nullptr))) return rc;                                    // :1252-1254
     int it = 0;
     for (; it < P.jacobi_iters; ++it) {
         if ((rc = mg_exchange(s, p, 0, 1))) return rc;        // A p reaches one plane into the neighbours
-        fsk::cg_apply_a(s->st, gw, Ap, p);                                             // :1259
-        if ((rc = dot(p, Ap, d_pap, nullptr))) return rc;                              // :1261
-        fsk::cg_update_xr(s->st, gw, x, r, p, Ap, fsk::CgScalar(d_zo, d_pap));         // :1263, :1266
-        if ((rc = dot(r, r, d_rtr, &rTr))) return rc;                                  // :1269-1271
+        // :1259 and the products of :1261 over the owned planes
+        fsk::cg_apply_a_dot(s->st, gw, Ap, p, s->cg_partial, d_pap, W.lo, W.lo + W.nzl);
+        if ((rc = cg_sum_all(s, d_pap, nullptr))) return rc;
+        // :1263, :1266 and :1269-1271
+        fsk::cg_update_xr_dot(s->st, gw, x, r, p, Ap, fsk::CgScalar(d_zo, d_pap), s->cg_partial, d_rtr, W.lo,
+                              W.lo + W.nzl);
+        if ((rc = cg_sum_all(s, d_rtr, &rTr))) return rc;
         if (rTr < P.iter_precision || rTr == 0) {                                      // :1275
             ++it;
             break;
         }
-        if ((rc = mg_exchange(s, r, 0, s->mg_G))) return rc;  // the V-cycle starts from exact ghost planes
+        if ((rc = mg_exchange(s, r, 0, W.G))) return rc;      // the V-cycle starts from exact ghost planes
         if ((rc = mg_precondition_slab(s))) return rc;                                 // :1279
+        z = s->cg_z;
         if ((rc = dot(z, r, d_zn, nullptr))) return rc;                                // :1285-1287
         fsk::cg_update_p(s->st, gw, p, z, fsk::CgScalar(d_zn, d_zo));                  // :1288-1290
         std::swap(d_zo, d_zn);
@@ -1112,25 +1142,39 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             break;
         }
         if (p->pressure_solver == FS_PRESSURE_MGPCG && world > 1) {
-            // windows of the levels: owned planes plus G ghost planes per non-wall side, G as deep
-            // as the coarsest level's slab allows (at most 4)
+            // windows of the levels: owned planes plus G ghost planes per non-wall side.  G planes
+            // last G colours of smoothing between two exchanges, so the coarse levels, whose planes
+            // are small and whose sweeps are many, get deeper ghosts than the fine ones (a level
+            // with large planes: 4, what one blocked pass uses up); never deeper than the slab of
+            // the level, nor than twice the next coarser level's (prolongation halves the depth).
+            // FS_MG_SLAB_GHOST caps every level (tests).
             const int L = p->mg_level;
-            int G = g.nzl >> (L - 1);
-            if (G > 4) G = 4;
-            s->mg_G = G;
+            int cap_all = 1 << 20;
+            if (const char* e = getenv("FS_MG_SLAB_GHOST"))
+                if (atoi(e) >= 1) cap_all = atoi(e);
+            int Gs[16];
+            for (int l = L - 1; l >= 0; --l) {
+                const long plane = (long)(g.nx >> l) * (g.ny >> l);
+                int G = plane >= 128L * 128L ? 4 : plane >= 64L * 64L ? 8 : 16;
+                if (G > (g.nzl >> l)) G = g.nzl >> l;
+                if (l < L - 1 && G > 2 * Gs[l + 1]) G = 2 * Gs[l + 1];
+                if (G > cap_all) G = cap_all;
+                Gs[l] = G;
+            }
             size_t off = 0;
             for (int l = 0; l < L; ++l) {
                 fs_solver::MgWin W{};
                 W.nx = g.nx >> l; W.ny = g.ny >> l; W.nz = g.nz >> l;
                 W.z0 = g.z0 >> l; W.nzl = g.nzl >> l;
-                W.lo = g.wall_lo ? 0 : G; W.hi = g.wall_hi ? 0 : G;
+                W.G = Gs[l];
+                W.lo = g.wall_lo ? 0 : W.G; W.hi = g.wall_hi ? 0 : W.G;
                 W.off = off;
                 W.vz = 0;
                 off += (W.cell() * W.held() + 63) & ~(size_t)63;
                 s->mgw.push_back(W);
             }
             const size_t space_al = off, n = (s->mgw[0].cell() * s->mgw[0].held() + 63) & ~(size_t)63;
-            const size_t total = (2 * space_al + 3 * n) * sizeof(float);
+            const size_t total = (3 * space_al + 3 * n) * sizeof(float);
             e = hipMalloc((void**)&s->cg_r, total);
             if (e != hipSuccess || hipMemsetAsync(s->cg_r, 0, total, s->st) != hipSuccess ||
                 hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 4) * sizeof(double)) != hipSuccess ||
@@ -1139,7 +1183,8 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                 break;
             }
             s->cg_z = s->cg_r + space_al;
-            s->cg_p = s->cg_z + space_al;
+            s->cg_zalt = s->cg_z + space_al;
+            s->cg_p = s->cg_zalt + space_al;
             s->cg_Ap = s->cg_p + n;
             s->cg_x = s->cg_Ap + n;
             s->cg_out = s->cg_partial + fsk::cg_dot_partials();

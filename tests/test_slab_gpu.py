@@ -119,17 +119,24 @@ def test_slab_confinement_needs_slabs_as_thick_as_its_reach(fs):
     assert b"upper neighbour" in L.fs_last_error()
 
 
-@pytest.mark.parametrize("world,dims,steps,extra", [
-    (2, (16, 24, 32), 4, ["mgpcg"]),                       # 16 planes per rank: 2 ghost planes per level
-    (3, (16, 16, 96), 3, ["mgpcg", "random"]),             # 32 planes per rank: 4 ghost planes, interior rank
-    (2, (24, 16, 64), 3, ["mgpcg", "confine"]),            # the configuration the reference ships
+@pytest.mark.parametrize("world,dims,steps,extra,env", [
+    (2, (16, 24, 32), 4, ["mgpcg"], {}),                        # 16 planes per rank, coarsest level 2 planes
+    (3, (16, 16, 96), 3, ["mgpcg", "random"], {}),              # 32 planes per rank, interior rank
+    (2, (24, 16, 64), 3, ["mgpcg", "confine"], {}),             # the configuration the reference ships
+    # every level the blocked kernel can take goes through it, four colours per pass (ghost depth 4)
+    (2, (32, 32, 64), 3, ["mgpcg", "random"], {"FS_MG_TB_MIN": "0", "FS_MG_SLAB_GHOST": "4"}),
+    # ... two colours per pass (ghost depth 2), three ranks
+    (3, (32, 16, 96), 2, ["mgpcg"], {"FS_MG_TB_MIN": "0", "FS_MG_SLAB_GHOST": "2"}),
+    # one ghost plane: an exchange before every colour
+    (2, (16, 16, 32), 2, ["mgpcg"], {"FS_MG_SLAB_GHOST": "1"}),
 ])
-def test_slab_mgpcg(world, dims, steps, extra):
+def test_slab_mgpcg(world, dims, steps, extra, env):
     """FS_PRESSURE_MGPCG on slabs: every rank runs the V-cycle and the CG vector operations on its
     window of each level (owned planes plus ghost planes that are refreshed before the error of the
     window's edge can reach an owned plane), dot products are all-reduced.  Iteration counts equal
     the single-domain oracle's, fields agree to 1e-5."""
-    run_ranks(world, ["host", *dims, steps, 30, *extra], 29750 + world + len(extra))
+    port = 29750 + world + 3 * len(extra) + 7 * len(env) + (11 if "FS_MG_SLAB_GHOST" in env and env["FS_MG_SLAB_GHOST"] == "2" else 0)
+    run_ranks(world, ["host", *dims, steps, 30, *extra], port, env)
 
 
 def test_slab_mgpcg_needs_slabs_that_coarsen_on_their_own(fs):
