@@ -1158,6 +1158,10 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                 int G = plane >= 128L * 128L ? 4 : plane >= 64L * 64L ? 8 : 16;
                 if (G > (g.nzl >> l)) G = g.nzl >> l;
                 if (l < L - 1 && G > 2 * Gs[l + 1]) G = 2 * Gs[l + 1];
+                // level 0 starts as r = -div on every held plane, and the divergence field has
+                // pghost ghost planes: its window must not reach beyond them
+                if (l == 0 && G > 4) G = 4;
+                if (l == 0 && G > g.pghost) G = g.pghost;
                 if (G > cap_all) G = cap_all;
                 Gs[l] = G;
             }
