@@ -253,6 +253,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    # this driver shares device memory between processes through dmabuf only; without the setting
+    # RCCL fails with hipIpcGetMemHandle: invalid argument (read when the HSA runtime starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     # gloo and RCCL announce themselves on stdout (connections, a version banner); the one JSON
     # line must stay alone there, so everything else this process and its libraries print goes to
     # stderr and the line is written to the original stdout at the end
