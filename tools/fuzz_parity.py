@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the single-GPU solver against the CPU oracle.
 
-    python tools/fuzz_parity.py [cases] [seed] [seconds]
+    python tools/fuzz_parity.py [cases] [seed] [seconds] [share of medium-sized grids]
 
 Every case draws a grid shape (odd extents, extents of 1, multiples of 4 and 8, thin and flat
 grids), a scheme, a sweep count, optional vorticity confinement, the MGPCG solver where the shape
@@ -21,10 +21,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+MEDIUM = 0.0    # share of medium-sized grids (fourth argument)
+
+
 def draw_dims(rng, mgpcg):
     if mgpcg:
         return tuple(int(8 * rng.integers(1, 9)) for _ in range(3))
     kind = rng.integers(0, 5)
+    if rng.random() < MEDIUM:      # several tiles in x and y, several z chunks, many workgroups
+        return (int(4 * rng.integers(30, 100)), int(rng.integers(100, 330)), int(rng.integers(20, 130)))
     if kind == 0:
         return tuple(int(rng.integers(1, 40)) for _ in range(3))
     if kind == 1:      # rows the blocked pressure kernel takes (nx % 4 == 0), ragged elsewhere
@@ -44,6 +49,8 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+    global MEDIUM
+    MEDIUM = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
     import fluidsolver_amd as fs
     import oracle
     from conftest import random_fields
@@ -105,7 +112,7 @@ def main():
         if bad:
             failed += 1
             print("FAIL " + desc + " :: " + "; ".join(bad[:3]), flush=True)
-        elif case % 20 == 0:
+        elif case % (20 if MEDIUM == 0 else 5) == 0:
             print("ok   " + desc, flush=True)
     print("%d cases, %d failed, %.0f s (seed %d)" % (done, failed, time.time() - t_start, seed), flush=True)
     sys.exit(1 if failed else 0)
