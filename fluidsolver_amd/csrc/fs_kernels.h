@@ -139,6 +139,8 @@ void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, dou
 //  the operator and the update cover all of g either way; k_hi < 0 = all planes)
 void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, double* partial, double* out,
                     int k_lo = 0, int k_hi = -1);
+void cg_update_p_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, float* pn, const float* po, const float* z,
+                             CgScalar beta, double* partial, double* out);
 void cg_update_xr_dot(hipStream_t st, const FsGrid& g, float* x, float* r, const float* p, const float* Ap,
                       CgScalar alpha, double* partial, double* out, int k_lo = 0, int k_hi = -1);
 float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, float* zalt, int levels,

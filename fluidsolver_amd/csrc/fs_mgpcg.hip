@@ -285,6 +285,58 @@ k_apply_a_dot4(float* __restrict__ Ap, const float* __restrict__ p, Dim3i d, dou
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// p' = z + beta p (Solver.cu:1290), A p' and the partial sums of p' . A p' in one pass: the new p of
+// the six neighbours is formed again from z and the old p (the same expression, so the same values
+// as the neighbours store), which is why p' goes to a second array.
+__global__ void __launch_bounds__(kDotBlock)
+k_update_p_apply_a_dot4(float* __restrict__ Ap, float* __restrict__ pn, const float* __restrict__ po,
+                        const float* __restrict__ z, CgScalar coef, Dim3i d, double* __restrict__ partial)
+{
+    __shared__ double sh[kDotBlock / 64];
+    const unsigned nx4 = (unsigned)d.x >> 2, items = nx4 * (unsigned)d.y * (unsigned)d.z;
+    const size_t sy = (size_t)d.x, sz = (size_t)d.x * d.y;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float beta = cg_scalar(coef);
+    auto p1 = [&](size_t o) { return z[o] + beta * po[o]; };
+    auto p4 = [&](size_t o) {
+        const f4 zz = *(const f4*)(z + o), pp = *(const f4*)(po + o);
+        return f4{zz.x + beta * pp.x, zz.y + beta * pp.y, zz.z + beta * pp.z, zz.w + beta * pp.w};
+    };
+    double s = 0.0;
+    for (unsigned it = blockIdx.x * kDotBlock + threadIdx.x; it < items; it += gridDim.x * kDotBlock) {
+        const unsigned i4 = it % nx4, rest = it / nx4;
+        const int j = (int)(rest % (unsigned)d.y), k = (int)(rest / (unsigned)d.y);
+        const size_t ind = (size_t)4 * i4 + (size_t)j * sy + (size_t)k * sz;
+        const f4 c = p4(ind);
+        const float lft = i4 > 0 ? p1(ind - 1) : 0.f, rgt = i4 + 1 < nx4 ? p1(ind + 4) : 0.f;
+        const f4 dn = j > 0 ? p4(ind - sy) : zero, up = j + 1 < d.y ? p4(ind + sy) : zero;
+        const f4 bk = k > 0 ? p4(ind - sz) : zero, fw = k + 1 < d.z ? p4(ind + sz) : zero;
+        f4 a;
+        a.x = 6.f * c.x - (lft + c.y + dn.x + up.x + bk.x + fw.x);
+        a.y = 6.f * c.y - (c.x + c.z + dn.y + up.y + bk.y + fw.y);
+        a.z = 6.f * c.z - (c.y + c.w + dn.z + up.z + bk.z + fw.z);
+        a.w = 6.f * c.w - (c.z + rgt + dn.w + up.w + bk.w + fw.w);
+        *(f4*)(pn + ind) = c;
+        *(f4*)(Ap + ind) = a;
+        s += (double)(c.x * a.x);
+        s += (double)(c.y * a.y);
+        s += (double)(c.z * a.z);
+        s += (double)(c.w * a.w);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// p' = z + beta p into another array
+__global__ void k_update_p2(float* __restrict__ pn, const float* __restrict__ po, const float* __restrict__ z,
+                            CgScalar coef, size_t n)
+{
+    const size_t ind = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ind >= n) return;
+    const float beta = cg_scalar(coef);
+    pn[ind] = z[ind] + beta * po[ind];
+}
+
 // k_update_xr and the partial sums of the new r . r
 __global__ void __launch_bounds__(kDotBlock)
 k_update_xr_dot4(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ p,
@@ -441,6 +493,23 @@ void cg_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, const float* p, 
     const Dim3i d{g.nx, g.ny, g.nz};
     const int blocks = dot_blocks((size_t)g.nx / 4 * g.ny * g.nz);
     hipLaunchKernelGGL(k_apply_a_dot4, dim3(blocks), dim3(kDotBlock), 0, st, Ap, p, d, partial, k_lo, k_hi);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
+}
+
+// pn = z + beta po, Ap = A pn and *out = pn . Ap
+void cg_update_p_apply_a_dot(hipStream_t st, const FsGrid& g, float* Ap, float* pn, const float* po, const float* z,
+                             CgScalar beta, double* partial, double* out)
+{
+    if (g.nx % 4 != 0) {
+        const size_t n = (size_t)g.nx * g.ny * g.nz;
+        hipLaunchKernelGGL(k_update_p2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pn, po, z, beta, n);
+        cg_apply_a(st, g, Ap, pn);
+        cg_dot(st, g, pn, Ap, partial, out);
+        return;
+    }
+    const Dim3i d{g.nx, g.ny, g.nz};
+    const int blocks = dot_blocks((size_t)g.nx / 4 * g.ny * g.nz);
+    hipLaunchKernelGGL(k_update_p_apply_a_dot4, dim3(blocks), dim3(kDotBlock), 0, st, Ap, pn, po, z, beta, d, partial);
     hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kDotBlock), 0, st, partial, blocks, out);
 }
 

@@ -137,6 +137,7 @@ struct fs_solver {
     float* vort[3] = {};              // dense vorticity arrays (one allocation), FS_FLAG_VORT_CONFINE only
     // MGPCG work arrays (one allocation): r, z over all levels, p, Ap, x on the fine grid
     float *cg_r = nullptr, *cg_z = nullptr, *cg_zalt = nullptr, *cg_p = nullptr, *cg_Ap = nullptr, *cg_x = nullptr;
+    float* cg_p2 = nullptr;           // single GPU: the second p array of the fused p-update / operator pass
     double *cg_partial = nullptr, *cg_out = nullptr;
     double* h_dot = nullptr;          // pinned
     // MGPCG on a z-slab: this rank's window of every level (owned planes plus G ghost planes per
@@ -754,11 +755,17 @@ int run_mgpcg(fs_solver* s)
         if ((rc = cg_read_sum(s, &rTr))) return rc;
     }
     precondition();                                               // :1244
-    fsk::cg_update_p(s->st, g, p, z, 0.f);                        // :1250
     fsk::cg_dot(s->st, g, z, r, s->cg_partial, d_zo);             // old_zTr :1252-1254
+    // p = z + beta p (:1250 with beta = 0, :1290 afterwards) is formed by the operator pass that
+    // needs it, into the other of two p arrays
+    float* p2 = s->cg_p2;
+    fsk::CgScalar beta(0.f);
+    if (P.jacobi_iters <= 0) fsk::cg_update_p(s->st, g, p, z, beta);
     int it = 0;
     for (; it < P.jacobi_iters; ++it) {
-        fsk::cg_apply_a_dot(s->st, g, Ap, p, s->cg_partial, d_pap);   // :1259 and the products of :1261
+        // :1250 / :1290, :1259 and the products of :1261
+        fsk::cg_update_p_apply_a_dot(s->st, g, Ap, p2, p, z, beta, s->cg_partial, d_pap);
+        std::swap(p, p2);
         // alpha = old_zTr / pAp :1263, then :1266 and :1269-1271
         fsk::cg_update_xr_dot(s->st, g, x, r, p, Ap, fsk::CgScalar(d_zo, d_pap), s->cg_partial, d_rtr);
         if ((rc = cg_read_sum(s, &rTr))) return rc;
@@ -768,9 +775,11 @@ int run_mgpcg(fs_solver* s)
         }
         precondition();                                           // :1279
         fsk::cg_dot(s->st, g, z, r, s->cg_partial, d_zn);         // new_zTr :1285-1287
-        fsk::cg_update_p(s->st, g, p, z, fsk::CgScalar(d_zn, d_zo));   // beta = new_zTr / old_zTr :1288-1290
+        beta = fsk::CgScalar(d_zn, d_zo);                         // new_zTr / old_zTr :1288, used by the next pass
         std::swap(d_zo, d_zn);
     }
+    s->cg_p = p;
+    s->cg_p2 = p2;
     s->last_sweeps = it;
     s->cg_rtr = rTr;
     // swap(&res, &x) at :1295 exchanges the by-value argument with the member x: the first solve
@@ -1195,7 +1204,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
         } else if (p->pressure_solver == FS_PRESSURE_MGPCG) {
             const size_t space = fsk::mg_space(g, p->mg_level), n = (size_t)g.nx * g.ny * g.nz;
             const size_t space_al = (space + 63) & ~(size_t)63;   // keeps every array 256-byte aligned
-            const size_t total = (3 * space_al + 3 * n) * sizeof(float);
+            const size_t total = (3 * space_al + 4 * n) * sizeof(float);
             e = hipMalloc((void**)&s->cg_r, total);
             if (e != hipSuccess || hipMemsetAsync(s->cg_r, 0, total, s->st) != hipSuccess ||
                 hipMalloc((void**)&s->cg_partial, (fsk::cg_dot_partials() + 4) * sizeof(double)) != hipSuccess ||
@@ -1208,6 +1217,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             s->cg_p = s->cg_zalt + space_al;
             s->cg_Ap = s->cg_p + n;
             s->cg_x = s->cg_Ap + n;
+            s->cg_p2 = s->cg_x + n;
             s->cg_out = s->cg_partial + fsk::cg_dot_partials();
         }
         if (p->flags & FS_FLAG_VORT_CONFINE) {
