@@ -22,7 +22,9 @@ def run_ranks(world, args, port, env_extra=None):
     # a stuck worker dumps its Python stacks and exits after 100 s, a stalled exchange reports the
     # queue states after 40 s: either ends the run well before the launcher's own limit
     env = dict({"FS_WORKER_DUMP_AFTER": "100", "FS_XCHG_TIMEOUT_MS": "40000"}, **os.environ)
-    env.update(OMP_NUM_THREADS="4", **(env_extra or {}))
+    # (every rank steps its own oracle: small teams that sleep in their barriers, or the ranks'
+    #  spinning threads starve one another on a box with few cores)
+    env.update(OMP_NUM_THREADS="4", OMP_WAIT_POLICY="passive", **(env_extra or {}))
     try:
         r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            timeout=160, text=True)

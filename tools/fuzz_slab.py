@@ -30,6 +30,10 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
     which = sys.argv[4] if len(sys.argv) > 4 else "all"
+    # every rank steps its own copy of the oracle: keep the ranks' OpenMP teams within the cores
+    # (oversubscribed teams spin in the barriers of the small multigrid loops for seconds)
+    os.environ["OMP_NUM_THREADS"] = str(max(1, 8 // int(os.environ.get("WORLD_SIZE", "1"))))
+    os.environ["OMP_WAIT_POLICY"] = "passive"
     import torch
     import torch.distributed as dist
     import fluidsolver_amd as fs
@@ -78,6 +82,8 @@ def main():
             case, nx, ny, nz, world, scheme, k, confine, mgpcg, steps, vel, os.environ["FS_JACOBI_CFG"])
         bad = []
         s = o = None
+        t_case = time.time()
+        t_gpu = t_cpu = 0.0
         try:
             s = SlabSolver(fs.default_params(nx, ny, nz, **gkw), rank, world, transport="host").Initialize()
             created = 1
@@ -101,9 +107,13 @@ def main():
                 o.set(fid, arr)
             try:
                 for step in range(steps):
+                    t0 = time.time()
                     s.step()
                     s.sync()
+                    t1 = time.time()
                     o.step()
+                    t_gpu += t1 - t0
+                    t_cpu += time.time() - t1
                     if mgpcg and s.cg_info()[0] != o.cg_info()[0]:
                         bad.append("step %d: %d vs %d CG iterations" % (step, s.cg_info()[0], o.cg_info()[0]))
                     for f in range(6):
@@ -135,7 +145,7 @@ def main():
                 print("FAIL " + desc + " :: " + "; ".join("rank %d: %s" % (r, ", ".join(b)) for r, b in enumerate(nbad) if b),
                       flush=True)
         elif rank == 0 and case % 5 == 0:
-            print("ok   " + desc, flush=True)
+            print("ok   " + desc + "  [%.1f s: slabs %.2f, oracle %.2f]" % (time.time() - t_case, t_gpu, t_cpu), flush=True)
     if rank == 0:
         print("%d cases on %d ranks, %d failed, %d refused by every rank and skipped, %.0f s (seed %d)" % (
             done, world, failed, skipped, time.time() - t_start, seed), flush=True)
