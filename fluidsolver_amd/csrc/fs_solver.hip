@@ -149,6 +149,7 @@ struct fs_solver {
         int lo, hi;        // ghost planes held below / above: G, or 0 at a wall
         size_t off;        // offset of the window inside r and z
         int vz;
+        int tb;            // the blocked smoother takes this level: -1 not tried yet, 0 no, 1 yes
         size_t cell() const { return (size_t)nx * ny; }
         int held() const { return lo + nzl + hi; }
     };
@@ -854,7 +855,7 @@ int mg_smooth_slab(fs_solver* s, int l, int steps, bool from_zero, float*& z, fl
     float* r = s->cg_r + W.off;
     const int kpar = (W.z0 - W.lo) & 1, phases = 2 * steps;
     // (the blocked kernel takes the colour of a cell from the window's own plane numbers)
-    bool blocked = kpar == 0 && W.G >= 2;
+    bool blocked = kpar == 0 && W.G >= 2 && W.tb != 0;
     for (int ph = 0; ph < phases;) {
         int take = 1;
         if (blocked) take = (phases - ph >= 4 && W.G >= 4) ? 4 : 2;
@@ -868,7 +869,9 @@ int mg_smooth_slab(fs_solver* s, int l, int steps, bool from_zero, float*& z, fl
         }
         if (blocked && fsk::mgs_smooth_pass(s->st, r, z, zalt, W.nx, W.ny, W.held(), take, zero_in)) {
             std::swap(z, zalt);
+            W.tb = 1;
         } else {
+            if (blocked) W.tb = 0;   // (a matter of the level's shape: the same answer on every rank, every time)
             blocked = false;
             take = 1;
             fsk::mgs_smooth_phase(s->st, r, z, W.nx, W.ny, W.held(), ph, kpar);
@@ -1183,6 +1186,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
                 W.lo = g.wall_lo ? 0 : W.G; W.hi = g.wall_hi ? 0 : W.G;
                 W.off = off;
                 W.vz = 0;
+                W.tb = -1;
                 off += (W.cell() * W.held() + 63) & ~(size_t)63;
                 s->mgw.push_back(W);
             }
