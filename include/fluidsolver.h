@@ -83,6 +83,11 @@ typedef struct fs_params {
     float dt;                    /* Solver.h:71   0.2  */
     int jacobi_iters;            /* Solver.h:68   max_iter = 30, sweeps per step */
     int scheme;                  /* Solver.cu:11  FS_SCHEME_MACCORMACK */
+    /* Source sphere (SourceKernel, Solver.cu:295-307).  The test (x-sx)^2 + (y-sy)^2 + (z-sz)^2 <= r^2
+       squares binary32 differences; the reference writes pow(v, 2).  The two agree whenever the
+       differences square exactly in binary32, which holds for centres on multiples of 1/2 (the
+       reference's own Nx/2, 10, Nz/2) and fractions with a few bits; for other centres a cell on
+       the rim of the sphere may fall on the other side. */
     float source_x;              /* Solver.h:78   Nx/2 */
     float source_y;              /* Solver.h:79   10   */
     float source_z;              /* Solver.h:80   Nz/2 */
