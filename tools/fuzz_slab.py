@@ -2,7 +2,7 @@
 """Randomised parity sweep of the z-slab decomposition against the single-domain CPU oracle.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node W --master-addr 127.0.0.1 \
-        --master-port P tools/fuzz_slab.py [cases] [seed] [seconds] [jacobi|mgpcg|all]
+        --master-port P tools/fuzz_slab.py [cases] [seed] [seconds] [jacobi|mgpcg|medium|all]
 
 All ranks (sharing whatever GPUs the box has, host-staged halos over gloo) draw the same cases from
 the same seed: grid shape (ragged slabs, thin slabs of 5 planes, slabs thick enough for the paired
@@ -62,6 +62,9 @@ def main():
             nx = int(rng.choice([int(rng.integers(1, 40)), int(4 * rng.integers(2, 30))]))
             ny = int(rng.integers(1, 70))
             nz = int(world * 5 + rng.integers(0, 30 * world))
+            if which == "medium":     # several tiles per plane, slabs thick enough for the paired pressure passes
+                nx, ny = int(4 * rng.integers(20, 60)), int(rng.integers(60, 200))
+                nz = int(world * 20 + rng.integers(0, 30 * world))
         scheme = int(rng.integers(0, 2))
         k = 30 if mgpcg else int(rng.integers(0, 26))
         confine = bool(rng.random() < 0.3)
