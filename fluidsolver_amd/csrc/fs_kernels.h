@@ -168,8 +168,11 @@ size_t vort_elems(const FsGrid& g);
 int vort_halo_planes(const FsGrid& g);
 void find_vort(hipStream_t st, const FsGrid& g, float* vortx, float* vorty, float* vortz, const float* ux,
                const float* uy, const float* uz);
+// lattice: vort_lattice_elems(g) floats of scratch for the |omega| values the faces share; without
+// it every face evaluates its own (one launch per component)
+size_t vort_lattice_elems(const FsGrid& g);
 void vort_confine(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* vortx,
-                  const float* vorty, const float* vortz, float coeff);
+                  const float* vorty, const float* vortz, float coeff, float* lattice = nullptr);
 // sum over owned cells of (div + 6p - neighbours)^2 in binary64; partial must hold
 // residual_partials(g) doubles, out one double.
 int residual_partials(const FsGrid& g);

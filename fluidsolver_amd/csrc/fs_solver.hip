@@ -135,6 +135,7 @@ struct fs_solver {
     hipStream_t st = nullptr;         // compute stream
     float* pool = nullptr;            // one allocation holding all 13 fields
     float* vort[3] = {};              // dense vorticity arrays (one allocation), FS_FLAG_VORT_CONFINE only
+    float* vort_lattice = nullptr;    // |omega| at the points the confined faces share
     // MGPCG work arrays (one allocation): r, z over all levels, p, Ap, x on the fine grid
     float *cg_r = nullptr, *cg_z = nullptr, *cg_zalt = nullptr, *cg_p = nullptr, *cg_Ap = nullptr, *cg_x = nullptr;
     float* cg_p2 = nullptr;           // single GPU: the second p array of the fused p-update / operator pass
@@ -1234,6 +1235,13 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
             }
             s->vort[1] = s->vort[0] + nv;
             s->vort[2] = s->vort[1] + nv;
+            // the |omega| lattices the faces share (FS_VORT_LATTICE=0: every face evaluates its own)
+            const char* le = getenv("FS_VORT_LATTICE");
+            if (!(le && atoi(le) == 0) &&
+                hipMalloc((void**)&s->vort_lattice, fsk::vort_lattice_elems(g) * sizeof(float)) != hipSuccess) {
+                rc = fail(FS_ERR_HIP, "fs_create: vorticity lattices (%zu bytes)", fsk::vort_lattice_elems(g) * sizeof(float));
+                break;
+            }
         }
         float** slots[nfields] = {&s->f.ux, &s->f.uy, &s->f.uz, &s->f.nux, &s->f.nuy, &s->f.nuz,
                                   &s->f.rho, &s->f.nrho, &s->f.T, &s->f.nT, &s->f.p, &s->f.np,
@@ -1385,6 +1393,7 @@ int fs_destroy(fs_solver* s)
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->pool) (void)hipFree(s->pool);
     if (s->vort[0]) (void)hipFree(s->vort[0]);
+    if (s->vort_lattice) (void)hipFree(s->vort_lattice);
     if (s->snap) (void)hipFree(s->snap);
     if (s->ev_snap) (void)hipEventDestroy(s->ev_snap);
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
@@ -1522,7 +1531,7 @@ int fs_stage_confine(fs_solver* s)
     FS_HIP(hipSetDevice(s->device));
     StageScope sc(s, FS_STAGE_CONFINE, 3);
     fsk::vort_confine(s->st, s->g, s->f.ux, s->f.uy, s->f.uz, s->vort[0], s->vort[1], s->vort[2],
-                      s->prm.curl_strength);
+                      s->prm.curl_strength, s->vort_lattice);
     s->vel_ghost = 0;
     s->div_fresh = false;
     FS_HIP(hipGetLastError());

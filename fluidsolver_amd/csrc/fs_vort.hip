@@ -182,6 +182,88 @@ __global__ void k_vort_confine(float* __restrict__ u, VortView vx, VortView vy, 
     else *dst += coeff * (gx * vyc - gy * vxc);
 }
 
+// ---- the same confinement with every |omega| evaluated once --------------------------------------
+// The six off-centre |omega| of a face lie half a cell from it along each axis.  Over the faces of
+// all three components those points form four lattices, each indexed like the cells/faces (i, j, k):
+//   A  (i+1/2, j+1/2, k+1/2)  cell centres          ux: i-1, i    uy: j-1, j    uz: k-1, k
+//   B  (i,     j,     k+1/2)  z-edge midpoints      ux: j, j+1    uy: i, i+1
+//   C  (i,     j+1/2, k    )  y-edge midpoints      ux: k, k+1    uz: i, i+1
+//   D  (i+1/2, j,     k    )  x-edge midpoints      uy: k, k+1    uz: j, j+1
+// (coordinates in cells; the taps and weights of a gather depend on the point alone, so a value read
+// from a lattice is bit for bit the value the face would have gathered itself).  k_vort_lattice
+// evaluates them for the planes the faces of this rank touch, k_vort_confine_all applies the force to
+// the three components from them: 4 instead of 18 evaluations per cell.
+struct Lattice {
+    float *A, *B, *C, *D;   // (nx+1) x (ny+1) x planes each, plane 0 = global plane k0
+    int sx, sxy, k0;
+    __device__ __forceinline__ size_t at(int i, int j, int k) const
+    {
+        return (size_t)i + (size_t)j * sx + (size_t)(k - k0) * sxy;
+    }
+};
+
+__global__ void k_vort_lattice(Lattice Lt, VortView vx, VortView vy, VortView vz, int nx, int ny, int kb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = kb + blockIdx.z;
+    if (i > nx || j > ny) return;
+    const VortTaps tx = make_taps(vx, i, j, k), ty = make_taps(vy, i, j, k), tz = make_taps(vz, i, j, k);
+    const size_t o = Lt.at(i, j, k);
+    // (P + D of vort_norm is twice the point's offset from (i, j, k))
+    Lt.A[o] = vort_norm<0, 1, 1, 1, 0, 0>(vx, tx, vy, ty, vz, tz);
+    Lt.B[o] = vort_norm<0, 1, 1, 0, -1, 0>(vx, tx, vy, ty, vz, tz);
+    Lt.C[o] = vort_norm<0, 1, 1, 0, 0, -1>(vx, tx, vy, ty, vz, tz);
+    Lt.D[o] = vort_norm<1, 0, 1, 0, 0, -1>(vx, tx, vy, ty, vz, tz);
+}
+
+// Solver.cu:586-604 for one face from its six |omega| and the vorticity at the face itself
+template <int DIR>
+__device__ __forceinline__ void confine_face(float* dst, float coeff, float vr, float vl, float vt, float vbo, float vf,
+                                             float vbh, float vxc, float vyc, float vzc)
+{
+    float gx = vr - vl;
+    float gy = vt - vbo;
+    float gz = vf - vbh;
+    // :593 -- the float sum meets a double literal: widened, double sqrt, narrowed on assignment
+    const float n = (float)sqrt((double)(gx * gx + gy * gy + gz * gz) + 1e-5);
+    gx /= n;
+    gy /= n;
+    gz /= n;
+    if (DIR == 1) *dst += coeff * (gy * vzc - gz * vyc);
+    else if (DIR == 2) *dst += coeff * (gz * vxc - gx * vzc);
+    else *dst += coeff * (gx * vyc - gy * vxc);
+}
+
+// All three components of the faces (i, j, k), k in [kb, kb + gridDim.z); the guards are those of the
+// reference's three launches (:548 with each component's own dims); kxy_end: first plane without ux
+// and uy faces of this rank (the shared uz face plane of a slab has none)
+__global__ void k_vort_confine_all(float* __restrict__ ux, float* __restrict__ uy, float* __restrict__ uz, Lattice Lt,
+                                   VortView vx, VortView vy, VortView vz, int nx, int ny, int nz, int pitch, int plane,
+                                   float coeff, int kb, int kxy_end)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = kb + blockIdx.z;
+    if (i > nx || j > ny || i < 3 || j < 3 || k < 3) return;
+    const VortTaps tx = make_taps(vx, i, j, k), ty = make_taps(vy, i, j, k), tz = make_taps(vz, i, j, k);
+    const size_t o = Lt.at(i, j, k);
+    const int off = i + j * pitch + k * plane;
+    float a, b, c;
+    if (k < kxy_end && i < nx + 1 - 2 && j < ny - 2 && k < nz - 2) {          // ux: dims (nx+1, ny, nz)
+        vort3<0, 1, 1, 0, 0, 0>(vx, tx, vy, ty, vz, tz, a, b, c);
+        confine_face<1>(ux + off, coeff, Lt.A[o], Lt.A[o - 1], Lt.B[o + Lt.sx], Lt.B[o], Lt.C[o + Lt.sxy], Lt.C[o], a, b, c);
+    }
+    if (k < kxy_end && i < nx - 2 && j < ny + 1 - 2 && k < nz - 2) {          // uy: dims (nx, ny+1, nz)
+        vort3<1, 0, 1, 0, 0, 0>(vx, tx, vy, ty, vz, tz, a, b, c);
+        confine_face<2>(uy + off, coeff, Lt.B[o + 1], Lt.B[o], Lt.A[o], Lt.A[o - Lt.sx], Lt.D[o + Lt.sxy], Lt.D[o], a, b, c);
+    }
+    if (i < nx - 2 && j < ny - 2 && k < nz + 1 - 2) {                          // uz: dims (nx, ny, nz+1)
+        vort3<1, 1, 0, 0, 0, 0>(vx, tx, vy, ty, vz, tz, a, b, c);
+        confine_face<3>(uz + off, coeff, Lt.C[o + 1], Lt.C[o], Lt.D[o + Lt.sx], Lt.D[o], Lt.A[o], Lt.A[o - Lt.sxy], a, b, c);
+    }
+}
+
 }  // namespace
 
 namespace fsk {
@@ -222,13 +304,51 @@ void find_vort(hipStream_t st, const FsGrid& g, float* vortx, float* vorty, floa
                        uz - zoff, g.nx, g.ny, g.nz, g.pitch, g.plane, g.z0);
 }
 
+// Planes of the |omega| lattices a rank holds: z0 - 1 (the cell centres below its first uz faces)
+// up to z0 + nzl (the planes above its last ux / uy faces, the plane of the shared uz faces).  The
+// gathers of those lattice points reach the vorticity planes z0 - 2 .. z0 + nzl + 1: at the top what
+// the faces' own gathers reach, at the bottom one plane more, which the window's halo also holds.
+static void lattice_planes(const FsGrid& g, int* kb, int* ke)
+{
+    *kb = max(g.z0 - 1, 0);
+    *ke = g.z0 + g.nzl + 1;
+}
+
+size_t vort_lattice_elems(const FsGrid& g)
+{
+    int kb, ke;
+    lattice_planes(g, &kb, &ke);
+    return 4 * (size_t)(g.nx + 1) * (g.ny + 1) * (size_t)(ke - kb);
+}
+
 void vort_confine(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* uz, const float* vortx,
-                  const float* vorty, const float* vortz, float coeff)
+                  const float* vorty, const float* vortz, float coeff, float* lattice)
 {
     const ptrdiff_t w = (ptrdiff_t)vort_first(g), zoff = (ptrdiff_t)g.z0 * g.plane;
     const VortView vx{vortx - w, g.nx, g.ny + 1, g.nz + 1}, vy{vorty - w, g.nx + 1, g.ny, g.nz + 1},
         vz{vortz - w, g.nx + 1, g.ny + 1, g.nz};
     dim3 block(64, 4);
+    if (lattice) {
+        int kb, ke;
+        lattice_planes(g, &kb, &ke);
+        Lattice Lt;
+        Lt.sx = g.nx + 1;
+        Lt.sxy = (g.nx + 1) * (g.ny + 1);
+        Lt.k0 = kb;
+        const size_t n = (size_t)Lt.sxy * (ke - kb);
+        Lt.A = lattice; Lt.B = lattice + n; Lt.C = lattice + 2 * n; Lt.D = lattice + 3 * n;
+        // faces with k in [3, nz - 2] read lattice planes k - 1 .. k + 1 (k + 1: ux and uy faces only)
+        const int lb = max(kb, 2), le = min(ke, g.nz);
+        if (le > lb)
+            hipLaunchKernelGGL(k_vort_lattice, dim3(cdiv(g.nx + 1, 64), cdiv(g.ny + 1, 4), le - lb), block, 0, st, Lt, vx,
+                               vy, vz, g.nx, g.ny, lb);
+        const int fb = max(g.z0, 3), fe = min(g.z0 + g.nzl + 1, g.nz - 1);
+        if (fe > fb)
+            hipLaunchKernelGGL(k_vort_confine_all, dim3(cdiv(g.nx + 1, 64), cdiv(g.ny + 1, 4), fe - fb), block, 0, st,
+                               ux - zoff, uy - zoff, uz - zoff, Lt, vx, vy, vz, g.nx, g.ny, g.nz, g.pitch, g.plane, coeff,
+                               fb, g.z0 + g.nzl);
+        return;
+    }
     {
         const int dx = g.nx + 1, dy = g.ny, dz = g.nz;
         hipLaunchKernelGGL(k_vort_confine<1>, dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl), block, 0, st, ux - zoff, vx, vy,
