@@ -271,10 +271,14 @@ def test_graph_replay_matches_eager_launches(fs, oracle, k):
     g.close(); e.close(); o.close()
 
 
-@pytest.mark.parametrize("dims", [(16, 20, 12), (9, 8, 10), (6, 6, 6), (70, 9, 11)])
-def test_vorticity_confinement_stages(fs, oracle, dims):
+@pytest.mark.parametrize("lattice", [1, 0])
+@pytest.mark.parametrize("dims", [(16, 20, 12), (9, 8, 10), (6, 6, 6), (70, 9, 11), (67, 70, 9)])
+def test_vorticity_confinement_stages(fs, oracle, dims, lattice, monkeypatch):
     """FS_FLAG_VORT_CONFINE: FindVort + ApplyVortConfinement from a random state, against the
-    oracle's literal gathers (mismatched strides, guard from the launch dims, double sqrt)."""
+    oracle's literal gathers (mismatched strides, guard from the launch dims, double sqrt); with
+    the |omega| values shared through the four lattices (default) and with every face evaluating
+    its own (FS_VORT_LATTICE=0)."""
+    monkeypatch.setenv("FS_VORT_LATTICE", str(lattice))
     nx, ny, nz = dims
     g, o = make_pair(fs, oracle, nx, ny, nz, flags=fs.FS_FLAG_VORT_CONFINE)
     o.close()

@@ -96,15 +96,16 @@ def test_slab_paired_passes_share_one_exchange(world, dims, steps, k, pghost):
               {"FS_SLAB_PGHOST": str(pghost), "FS_JACOBI_TUNE": "0"})
 
 
+@pytest.mark.parametrize("lattice", [1, 0])
 @pytest.mark.parametrize("world,dims,steps,k,extra", [
     (2, (24, 20, 32), 4, 8, ["confine"]),
     (3, (20, 16, 48), 3, 8, ["confine", "random"]),   # 8 halo planes of vorticity, 16 planes per rank
 ])
-def test_slab_vorticity_confinement(world, dims, steps, k, extra):
+def test_slab_vorticity_confinement(world, dims, steps, k, extra, lattice):
     """FS_FLAG_VORT_CONFINE on slabs: every rank holds its window of the vorticity arrays' flat
     index space and receives the planes its gathers reach in the neighbours' (the mismatched
     strides of the reference land a gather several planes above its face)."""
-    run_ranks(world, ["host", *dims, steps, k, *extra], 29740 + world)
+    run_ranks(world, ["host", *dims, steps, k, *extra], 29740 + world + 3 * lattice, {"FS_VORT_LATTICE": str(lattice)})
 
 
 def test_slab_confinement_needs_slabs_as_thick_as_its_reach(fs):
