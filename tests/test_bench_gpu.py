@@ -40,3 +40,16 @@ def test_two_ranks_launched_by_bench_itself():
     assert out["value"] == pytest.approx(64 * 64 * 128 * 2 / (out["ms_per_step"] * 2e-3), rel=1e-6)
     halos = out["config"]["workload"]
     assert ("RCCL" in halos and out["rccl_ranks"] == 2) or ("host buffers" in halos and out["rccl_ranks"] == 0), halos
+
+
+def test_two_ranks_strong_scaling_and_convergence_mode():
+    """The other multi-rank shapes of the benchmark: one grid cut into slabs (--scaling strong), and
+    the weak-scaling column swept until the all-reduced residual norm meets a tolerance."""
+    out, _ = run_bench(["--gpus", "2", "--size", "64", "--iters", "8", "--steps", "2", "--warmup", "1",
+                        "--scaling", "strong"])
+    assert out["scaling"] == "strong" and out["config"]["nz"] == 64 and out["n_gpus"] == 2
+    assert out["value"] == pytest.approx(64 ** 3 * 2 / (out["ms_per_step"] * 2e-3), rel=1e-6)
+    out, _ = run_bench(["--gpus", "2", "--size", "32", "--iters", "64", "--steps", "2", "--warmup", "1",
+                        "--tolerance", "1e-2", "--check-every", "8"])
+    assert out["scaling"] == "weak" and out["config"]["nz"] == 64
+    assert out["config"]["tolerance"] == 1e-2 and 8 <= out["config"]["sweeps_per_step_run"] <= 64
