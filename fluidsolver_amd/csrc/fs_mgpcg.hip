@@ -140,6 +140,88 @@ k_smooth_lds(const float* __restrict__ r, float* __restrict__ z, int steps, Dim3
     for (int c = threadIdx.x; c < n; c += kSmoothLdsThreads) z[c] = sz[c];
 }
 
+// The same for levels up to 16384 cells, with the work of a colour cut down to what it has to be.  z lives
+// in LDS inside a shell of zeros (the zero-outside operator needs no bounds tests then); a thread
+// owns up to ITEMS pairs of x-neighbouring cells for the whole launch - index, right-hand side and
+// parity are worked out once and stay in registers - and every colour updates the one cell of each
+// pair that has that colour: six LDS reads, the sum, the division, one LDS write.  (k_smooth_lds
+// decomposes a running index with two divisions and two modulos per cell and colour, which is most
+// of its time.)  Same expression and colour order as k_smooth.
+constexpr int kSmoothPadFloats = 34 * 34 * 18 + 2048;   // 91 KB: a 32 x 32 x 16 level in its shell, or a 16 x 32 x 32 one
+
+template <int ITEMS>
+__global__ void __launch_bounds__(kSmoothLdsThreads)
+k_smooth_pad(const float* __restrict__ r, float* __restrict__ z, int phases, int from_zero, Dim3i d)
+{
+    __shared__ float sz[kSmoothPadFloats];
+    const int px = d.x + 2, pxy = px * (d.y + 2), padded = pxy * (d.z + 2);
+    const int hx = (d.x + 1) >> 1, pairs = hx * d.y * d.z;
+    for (int c = threadIdx.x; c < padded; c += kSmoothLdsThreads) sz[c] = 0.f;
+    __syncthreads();
+    int pb[ITEMS];          // padded index of the pair's first cell; -1: no such pair
+    unsigned gi[ITEMS];     // its index in the level
+    float r0[ITEMS], r1[ITEMS];
+    int par[ITEMS];         // bit 0: parity of j + k, bit 1: the pair has a second cell
+#pragma unroll
+    for (int m = 0; m < ITEMS; ++m) {
+        const int c = threadIdx.x + m * kSmoothLdsThreads;
+        pb[m] = -1;
+        gi[m] = 0;
+        r0[m] = r1[m] = 0.f;
+        par[m] = 0;
+        if (c < pairs) {
+            const int t = c % hx, rest = c / hx, j = rest % d.y, k = rest / d.y;
+            const bool two = 2 * t + 1 < d.x;
+            pb[m] = (2 * t + 1) + (j + 1) * px + (k + 1) * pxy;
+            gi[m] = (unsigned)(2 * t + j * d.x + k * d.x * d.y);
+            par[m] = ((j + k) & 1) | (two ? 2 : 0);
+            r0[m] = r[gi[m]];
+            if (two) r1[m] = r[gi[m] + 1];
+            if (!from_zero) {
+                sz[pb[m]] = z[gi[m]];
+                if (two) sz[pb[m] + 1] = z[gi[m] + 1];
+            }
+        }
+    }
+    __syncthreads();
+    for (int ph = 0; ph < phases; ++ph) {
+#pragma unroll
+        for (int m = 0; m < ITEMS; ++m) {
+            const int q = (par[m] + ph) & 1;                  // which cell of the pair has this colour
+            if (pb[m] < 0 || (q && !(par[m] & 2))) continue;
+            const int ind = pb[m] + q;
+            const float rhs = q ? r1[m] : r0[m];
+            // x-1, x+1, y-1, y+1, z-1, z+1, summed left to right (neibor_sum)
+            sz[ind] = fsk::div6(rhs + (sz[ind - 1] + sz[ind + 1] + sz[ind - px] + sz[ind + px] + sz[ind - pxy] + sz[ind + pxy]));
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < ITEMS; ++m) {
+        if (pb[m] < 0) continue;
+        z[gi[m]] = sz[pb[m]];
+        if (par[m] & 2) z[gi[m] + 1] = sz[pb[m] + 1];
+    }
+}
+
+// k_smooth_pad for a level of d: false if it does not fit (nothing launched)
+static bool smooth_pad(hipStream_t st, const float* r, float* z, int phases, bool from_zero, Dim3i d)
+{
+    const long padded = (long)(d.x + 2) * (d.y + 2) * (d.z + 2);
+    const long pairs = (long)((d.x + 1) / 2) * d.y * d.z;
+    // (16 pairs per thread, a 32^3 level, would fit, but a colour then takes 4 us in the one
+    //  workgroup against 3.4 us as a launch of its own that fills 64 CUs: 16384 cells is the limit)
+    if (padded > kSmoothPadFloats || pairs > 8L * kSmoothLdsThreads) return false;
+    const int items = (int)((pairs + kSmoothLdsThreads - 1) / kSmoothLdsThreads);
+    const dim3 g(1), b(kSmoothLdsThreads);
+    const int fz = from_zero ? 1 : 0;
+    if (items <= 1) hipLaunchKernelGGL(k_smooth_pad<1>, g, b, 0, st, r, z, phases, fz, d);
+    else if (items <= 2) hipLaunchKernelGGL(k_smooth_pad<2>, g, b, 0, st, r, z, phases, fz, d);
+    else if (items <= 4) hipLaunchKernelGGL(k_smooth_pad<4>, g, b, 0, st, r, z, phases, fz, d);
+    else hipLaunchKernelGGL(k_smooth_pad<8>, g, b, 0, st, r, z, phases, fz, d);
+    return true;
+}
+
 // The eight SubRestrict launches of the reference, in their order, for one coarse cell: each
 // adds half the residual of one child (double product and sum, narrowed on the store).
 __global__ void k_restrict(const float* __restrict__ r, const float* __restrict__ z, float* __restrict__ rc, Dim3i d)
@@ -557,6 +639,12 @@ static long mg_tb_min_plane()
     return 128L * 128L;
 }
 
+static bool mg_pad_smoother()
+{
+    const char* e = getenv("FS_MG_LDS_PAD");
+    return !e || atoi(e) != 0;
+}
+
 static bool mg_no_lds_smoother()
 {
     const char* e = getenv("FS_MG_NO_LDS");   // tests: force the per-colour launches on small levels
@@ -591,6 +679,11 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
                 from_zero = false;
             }
         }
+        // levels up to 16384 cells: every colour in one workgroup (FS_MG_LDS_PAD=0: up to 8192 cells,
+        // through the older kernel)
+        if (phases > 0 && !mg_no_lds_smoother() && mg_pad_smoother() &&
+            smooth_pad(st, r + offset, cur[l], phases, from_zero, d))
+            return;
         if (from_zero) (void)hipMemsetAsync(cur[l], 0, (size_t)d.x * d.y * d.z * sizeof(float), st);
         if (phases > 0 && (size_t)d.x * d.y * d.z <= (size_t)kSmoothLdsCells && !mg_no_lds_smoother()) {
             hipLaunchKernelGGL(k_smooth_lds, dim3(1), dim3(kSmoothLdsThreads), 0, st, r + offset, cur[l], phases / 2, d);

@@ -419,7 +419,7 @@ def _mg_pair(fs, oracle, dims, **kw):
     return g, o
 
 
-@pytest.mark.parametrize("smoother", ["default", "blocked", "plain"])
+@pytest.mark.parametrize("smoother", ["default", "blocked", "plain", "lds2"])
 @pytest.mark.parametrize("dims", [(16, 24, 16), (32, 8, 24), (64, 128, 64), (256, 192, 32)])
 def test_mgpcg_steps_match_oracle(fs, oracle, dims, smoother, monkeypatch):
     """FS_PRESSURE_MGPCG (the shipped branch of Solver::Project) against the oracle's literal
@@ -427,15 +427,18 @@ def test_mgpcg_steps_match_oracle(fs, oracle, dims, smoother, monkeypatch):
     expressions; the dot products are binary64 sums of binary32 products on both sides (in a
     different but fixed order), narrowed to float, so results agree bit for bit unless a sum
     lands within ~1e-16 of a float rounding boundary -- asserted to 1e-5, exactness reported.
-    The red/black smoother runs as plain launches per colour or four colours per pass through the
-    temporally blocked kernel (by plane size; FS_MG_TB_MIN forces either)."""
-    if smoother != "default":
+    The red/black smoother runs as plain launches per colour, four colours per pass through the
+    temporally blocked kernel (by plane size; FS_MG_TB_MIN forces either), or every colour of a
+    level of up to 32^3 cells in one workgroup (two kernels: FS_MG_LDS_PAD)."""
+    if smoother == "lds2":
+        # the older single-workgroup smoother (z and right-hand side in LDS, levels up to 8192 cells)
+        monkeypatch.setenv("FS_MG_LDS_PAD", "0")
+    elif smoother != "default":
         monkeypatch.setenv("FS_MG_TB_MIN", "0" if smoother == "blocked" else "1000000000")
         # "plain" also takes the small levels through one launch per colour instead of the
         # single-workgroup LDS smoother
         monkeypatch.setenv("FS_MG_NO_LDS", "1" if smoother == "plain" else "0")
-    elif dims[0] != 256:
-        pytest.skip("the default threshold differs from 'plain' only on the large grid")
+
     steps = 2 if dims[0] == 256 else 3 if dims[0] == 64 else 5
     g, o = _mg_pair(fs, oracle, dims, jacobi_iters=30, source_y=min(10.0, dims[1] / 3.0),
                     source_radius=min(7.0, min(dims) / 4.0))
