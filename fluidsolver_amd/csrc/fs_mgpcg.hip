@@ -107,6 +107,21 @@ __global__ void k_smooth(const float* __restrict__ r, float* z, int phase, Dim3i
     z[ind] = fsk::div6(r[ind] + neibor_sum(z, i, j, k, d));
 }
 
+// Colour 0 of a level whose z is all zero, written together with the zeros of colour 1: a thread
+// per pair of x-neighbouring cells.  The neighbour sum of zeros is kept in the expression (it turns
+// a right-hand side of -0 into +0, as the general kernel does).
+__global__ void k_smooth_first(const float* __restrict__ r, float* __restrict__ z, Dim3i d)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+    if (2 * t >= d.x || j >= d.y) return;
+    const int q = (j + k) & 1;                    // the cell 2t + q has colour 0
+    const size_t base = (size_t)2 * t + (size_t)j * d.x + (size_t)k * d.x * d.y;
+    const float zero = 0.f;
+    const float nsum = zero + zero + zero + zero + zero + zero;
+    if (2 * t + q < d.x) z[base + q] = fsk::div6(r[base + q] + nsum);
+    if (2 * t + (q ^ 1) < d.x) z[base + (q ^ 1)] = 0.f;
+}
+
 // All colours of `steps` sweeps of a level that fits one workgroup's LDS (z and the right-hand side,
 // at most kSmoothLdsCells cells): the coarse levels of a V-cycle are a chain of tiny dependent
 // launches otherwise.  Same expression and colour order as k_smooth.
@@ -230,7 +245,7 @@ __global__ void k_restrict(const float* __restrict__ r, const float* __restrict_
     const int cx = d.x / 2, cy = d.y / 2;
     if (ci >= cx || cj >= cy) return;
     const size_t cind = (size_t)ci + (size_t)cj * cx + (size_t)ck * cx * cy;
-    float acc = rc[cind];
+    float acc = 0.f;   // (the reference accumulates onto a zeroed array)
 #pragma unroll
     for (int phase = 0; phase < 8; ++phase) {
         const int i = ci * 2 + (phase & 1), j = cj * 2 + ((phase >> 1) & 1), k = ck * 2 + ((phase >> 2) & 1);
@@ -265,7 +280,7 @@ __global__ void k_restrict_win(const float* __restrict__ r, const float* __restr
     const int cx = d.x / 2, cy = d.y / 2;
     if (ci >= cx || cj >= cy || ck >= cz) return;
     const size_t cind = (size_t)ci + (size_t)cj * cx + (size_t)ck * cx * cy;
-    float acc = rc[cind];
+    float acc = 0.f;   // (the reference accumulates onto a zeroed array)
 #pragma unroll
     for (int phase = 0; phase < 8; ++phase) {
         const int i = ci * 2 + (phase & 1), j = cj * 2 + ((phase >> 1) & 1), k = fk0 + ck * 2 + ((phase >> 2) & 1);
@@ -494,7 +509,7 @@ __global__ void k_restrict2(const float* __restrict__ r, const float* __restrict
         zzh[b] = k + 2 < d.z ? *(const f2*)(z + base + b * sy + 2 * sz) : zero;  // plane z = k+2
     }
     const size_t cind = (size_t)ci + (size_t)cj * cx + (size_t)ck * cx * cy;
-    float acc = rc[cind];
+    float acc = 0.f;   // (the reference accumulates onto a zeroed array)
 #pragma unroll
     for (int phase = 0; phase < 8; ++phase) {
         const int a = phase & 1, b = (phase >> 1) & 1, c = (phase >> 2) & 1;   // child offsets in x, y, z
@@ -657,8 +672,7 @@ static bool mg_no_lds_smoother()
 float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, float* zalt, int levels,
                        int init_smooth_steps, int bottom_smooth_steps)
 {
-    const size_t space = mg_space(g, levels), n0 = (size_t)g.nx * g.ny * g.nz;
-    if (space > n0) (void)hipMemsetAsync(r + n0, 0, (space - n0) * sizeof(float), st);
+    // (the coarse levels of r need no clearing: the restriction writes every cell of them)
     const long tb_min = mg_tb_min_plane();
     constexpr int kMaxLevels = 16;
     float* cur[kMaxLevels];      // array holding the current z of a level
@@ -684,14 +698,23 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
         if (phases > 0 && !mg_no_lds_smoother() && mg_pad_smoother() &&
             smooth_pad(st, r + offset, cur[l], phases, from_zero, d))
             return;
-        if (from_zero) (void)hipMemsetAsync(cur[l], 0, (size_t)d.x * d.y * d.z * sizeof(float), st);
+        const dim3 cgrid(cdiv(cdiv(d.x, 2), 32), cdiv(d.y, 4), d.z), cblock(32, 4);
         if (phases > 0 && (size_t)d.x * d.y * d.z <= (size_t)kSmoothLdsCells && !mg_no_lds_smoother()) {
+            if (from_zero) (void)hipMemsetAsync(cur[l], 0, (size_t)d.x * d.y * d.z * sizeof(float), st);
             hipLaunchKernelGGL(k_smooth_lds, dim3(1), dim3(kSmoothLdsThreads), 0, st, r + offset, cur[l], phases / 2, d);
-            phases = 0;
+            return;
         }
-        for (int i = 0; i < phases; ++i)   // red, black, red, ... (phases is even here)
-            hipLaunchKernelGGL(k_smooth, dim3(cdiv(cdiv(d.x, 2), 32), cdiv(d.y, 4), d.z), dim3(32, 4), 0, st,
-                               r + offset, cur[l], i & 1, d, 0);
+        int i = 0;
+        if (from_zero && phases > 0) {
+            // the first colour of a level that is all zero also writes the zeros of the other colour:
+            // no clearing pass
+            hipLaunchKernelGGL(k_smooth_first, cgrid, cblock, 0, st, r + offset, cur[l], d);
+            i = 1;
+        } else if (from_zero) {
+            (void)hipMemsetAsync(cur[l], 0, (size_t)d.x * d.y * d.z * sizeof(float), st);
+        }
+        for (; i < phases; ++i)   // red, black, red, ... (phases is even here)
+            hipLaunchKernelGGL(k_smooth, cgrid, cblock, 0, st, r + offset, cur[l], i & 1, d, 0);
     };
     for (; l < levels - 1; ++l) {
         cur[l] = z + offset; alt[l] = zalt + offset;

@@ -889,12 +889,12 @@ int mg_precondition_slab(fs_solver* s)
 {
     const fs_params& P = s->prm;
     const int L = P.mg_level;
-    // z of every level and the coarse levels of r start at zero
+    // z of every level starts at zero
     {
         const fs_solver::MgWin& W0 = s->mgw[0];
         const size_t n0 = W0.cell() * W0.held(), space = s->mgw[L - 1].off + s->mgw[L - 1].cell() * s->mgw[L - 1].held();
         FS_HIP(hipMemsetAsync(s->cg_z, 0, space * sizeof(float), s->st));
-        if (space > n0) FS_HIP(hipMemsetAsync(s->cg_r + n0, 0, (space - n0) * sizeof(float), s->st));
+        (void)n0;   // (the coarse levels of r need no clearing: restriction and exchange write every held plane)
     }
     float *z[16], *za[16];
     for (int l = 0; l < L; ++l) {
