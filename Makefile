@@ -18,25 +18,19 @@ all: $(LIB) $(SHIM) host oracle
 $(LIBDIR) $(BINDIR):
 	mkdir -p $@
 
-$(LIBDIR)/fs_kernels.o: $(CSRC)/fs_kernels.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
+KOBJS := fs_kernels fs_jacobi fs_advect fs_vort fs_mgpcg
+SOBJS := fs_solver fs_exchange fs_project_jacobi fs_project_mgpcg fs_stages fs_step
+OBJS  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(KOBJS) $(SOBJS)))
+
+# kernel translation units
+$(addprefix $(LIBDIR)/,$(addsuffix .o,$(KOBJS))): $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/fs_jacobi.o: $(CSRC)/fs_jacobi.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
+# host-side translation units behind the C ABI
+$(addprefix $(LIBDIR)/,$(addsuffix .o,$(SOBJS))): $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/fs_solver_impl.h $(CSRC)/fs_kernels.h include/fluidsolver.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/fs_vort.o: $(CSRC)/fs_vort.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-
-$(LIBDIR)/fs_mgpcg.o: $(CSRC)/fs_mgpcg.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-
-$(LIBDIR)/fs_advect.o: $(CSRC)/fs_advect.hip $(CSRC)/fs_kernels.h | $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-
-$(LIBDIR)/fs_solver.o: $(CSRC)/fs_solver.hip $(CSRC)/fs_kernels.h include/fluidsolver.h | $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-
-$(LIB): $(LIBDIR)/fs_kernels.o $(LIBDIR)/fs_jacobi.o $(LIBDIR)/fs_advect.o $(LIBDIR)/fs_vort.o $(LIBDIR)/fs_mgpcg.o $(LIBDIR)/fs_solver.o
+$(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -Wl,-rpath,/opt/rocm/lib -Wl,-soname,libfluidsolver.so
 
 $(SHIM): $(CSRC)/Solver.cpp include/Solver.h include/fluidsolver.h $(LIB)

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <initializer_list>
 
 namespace {
 // reference error convention: print and exit(1) (CuSolver/Include/CudaUtility.h:12-23)
@@ -57,6 +58,15 @@ void Solver::Update()
 void Solver::Advect() { check(fs_stage_advect(handle), "fs_stage_advect"); }
 
 void Solver::Project() { check(fs_stage_project(handle), "fs_stage_project"); }
+
+void Solver::ResetGridValue()
+{
+	for (int f : {FS_RHO, FS_UX, FS_UY, FS_UZ}) check(fs_field_fill(handle, f, 0.f), "fs_field_fill");
+}
+
+void Solver::Conjugate(float*, float*) { check(fs_stage_pressure_solve(handle), "fs_stage_pressure_solve"); }
+
+void Solver::MG_Preconditioner() { check(fs_mg_vcycle(handle), "fs_mg_vcycle"); }
 
 float* Solver::GetDensityField()
 {

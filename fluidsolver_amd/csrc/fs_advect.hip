@@ -675,22 +675,9 @@ k_advect_scalars_global(const float* __restrict__ T, float* __restrict__ nT,
 
 // FS_ADVECT_GLOBAL (timing experiments): bit 0 = velocity on the global path, bit 1 = scalars
 // on the global path.  Default: both through LDS bricks.
-int path_mask()
-{
-    static int v = [] {
-        const char* e = getenv("FS_ADVECT_GLOBAL");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
-// read per launch: tests run both bricks in one process
-bool narrow_brick()
-{
-    const char* e = getenv("FS_ADVECT_BRICK");
-    return !e || atoi(e) != 0;
-}
-bool use_global_path() { return (path_mask() & 1) != 0; }
-bool scalars_use_lds() { return (path_mask() & 2) == 0; }
+bool narrow_brick(const FsGrid& g) { return g.env.advect_brick != 0; }
+bool use_global_path(const FsGrid& g) { return (g.env.advect_global & 1) != 0; }
+bool scalars_use_lds(const FsGrid& g) { return (g.env.advect_global & 2) == 0; }
 
 #define FS_DISPATCH_MH(mac, halo, CALL)   \
     do {                                  \
@@ -727,7 +714,7 @@ void launch_component_global(hipStream_t st, float* out, const Vel& v, float dt,
 
 namespace fsk {
 
-int advect_velocity_launches(const FsGrid& g) { (void)g; return use_global_path() ? 3 : 2; }
+int advect_velocity_launches(const FsGrid& g) { return use_global_path(g) ? 3 : 2; }
 
 void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, float* nuz,
                      const float* ux, const float* uy, const float* uz, float dt, int scheme,
@@ -744,7 +731,7 @@ void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, fl
     const ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
     float *ox = nux - zoff, *oy = nuy - zoff, *oz = nuz - zoff;
     const int nzc = min(ze, zend) - zb;   // planes of [zb, ze) that hold ux / uy faces
-    if (use_global_path()) {
+    if (use_global_path(g)) {
         launch_component_global<1>(st, ox, v, dt, mac, halo, 0, 0, zb, g.nx + 1, g.ny, nzc, false, halo_flag);
         launch_component_global<2>(st, oy, v, dt, mac, halo, 0, 0, zb, g.nx, g.ny + 1, nzc, false, halo_flag);
         launch_component_global<3>(st, oz, v, dt, mac, halo, 0, 0, zb, g.nx, g.ny, ze - zb, false, halo_flag);
@@ -754,7 +741,7 @@ void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, fl
     Box B = make_box(kBX, kBY, kBZ, 0, 0, zb, g.nx, g.ny + 1, ze - zb);
 #define FS_CALL(M, H)                                                                              \
     do {                                                                                           \
-        if (narrow_brick())                                                                        \
+        if (narrow_brick(g))                                                                        \
             hipLaunchKernelGGL((k_advect_velocity_lds<DimsNarrow, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
                                ox, oy, oz, v, dt, B, zend, halo_flag);                             \
         else                                                                                       \
@@ -774,11 +761,11 @@ bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, 
         zb = g.z0;
         ze = g.z0 + g.nzl;
     }
-    if (ze <= zb) return div != nullptr && scalars_use_lds();
+    if (ze <= zb) return div != nullptr && scalars_use_lds(g);
     Vel v = make_vel(g, ux, uy, uz, owned_only);
     const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0;
     const ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
-    if (!scalars_use_lds()) {
+    if (!scalars_use_lds(g)) {
         Box B = make_box(64, 4, 1, 0, 0, zb, g.nx, g.ny, ze - zb);
 #define FS_CALL(M, H)                                                                             \
     hipLaunchKernelGGL((k_advect_scalars_global<M, H, 64, 4, 1>), dim3(B.nb), dim3(256), 0, st,   \
@@ -794,7 +781,7 @@ bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, 
                        nT - zoff, rho - zoff, nrho - zoff, dv, v, dt, B, halo_flag)
 #define FS_CALL(M, H)                                                                             \
     do {                                                                                          \
-        if (narrow_brick()) {                                                                     \
+        if (narrow_brick(g)) {                                                                     \
             if (dv) FS_CALL2(DimsNarrow, M, H, true);                                             \
             else FS_CALL2(DimsNarrow, M, H, false);                                               \
         } else {                                                                                  \

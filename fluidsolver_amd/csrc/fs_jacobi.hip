@@ -67,6 +67,7 @@ struct TbArgs {
     int lz;              // output planes per workgroup along z
     int tiles_x, tiles_y, nblocks;
     int order;           // 0: plain block order, 1: XCD-contiguous (z-chunk, y, x) order
+    int kpar;            // kRbgs: parity of the global z index of plane 0 (a slab's window may start on an odd plane)
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs, so ids b and b+8 share an L2.  Give each
@@ -141,7 +142,7 @@ struct TbRange {
 //   kJacobi  a Jacobi sweep of the clamped (Neumann) pressure operator (Solver.cu:426-443)
 //   kRbgs    one colour of a red/black Gauss-Seidel sweep of the zero-outside operator, the
 //            multigrid smoother (Smooth, Solver.cu:848-860): level t updates the cells with
-//            (x + y + z + t - 1) even to (rhs + neibor_sum) / 6 and carries the others over, so a
+//            (x + y + z + kpar + t - 1) even to (rhs + neibor_sum) / 6 and carries the others over, so a
 //            pass of T levels is T/2 sweeps, red colour first.  `div` holds the right-hand side.
 //   kRbgsZero  kRbgs whose input is known to be all zero (the first smoothing of a V-cycle level):
 //              level 0 is not loaded
@@ -200,7 +201,7 @@ __device__ __forceinline__ void tb_level(int n, TbRegs<T, CPT>& R, const TbLane<
             const float s2 = d.z + (ctr.y + ctr.w + pbo.z + pt.z + pbh.z + pf.z);
             const float s3 = d.w + (ctr.z + rgt + pbo.w + pt.w + pbh.w + pf.w);
             // x is a multiple of 4: the colour of this level is cells 0, 2 or cells 1, 3 of the quad
-            const bool even = ((Z.y0 + L.row[c] + k + (t - 1)) & 1) == 0;
+            const bool even = ((Z.y0 + L.row[c] + k + A.kpar + (t - 1)) & 1) == 0;
             const float da = fsk::div6(even ? s0 : s1), db = fsk::div6(even ? s2 : s3);
             r = even ? f4{da, ctr.y, db, ctr.w} : f4{ctr.x, da, ctr.z, db};
         }
@@ -366,38 +367,13 @@ constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 // 0.56 ms, 192^3 0.667 vs 0.670, 256^3 1.11 vs 1.05, 384^3 4.16 vs 3.63.  FS_JACOBI_CFG overrides.
 int tb_config(const FsGrid& g)
 {
-    if (const char* e = getenv("FS_JACOBI_CFG")) {   // read per launch: tests switch it
-        const int v = atoi(e);
-        if (v >= 0 && v < kNumConfigs) return v;
-    }
+    if (g.env.jacobi_cfg >= 0 && g.env.jacobi_cfg < kNumConfigs) return g.env.jacobi_cfg;
     if (g.jacobi_tile > 0 && g.jacobi_tile <= kNumConfigs) return g.jacobi_tile - 1;
     return (long)g.nx * g.ny >= 224L * 224L ? 0 : 1;
 }
 
-// FS_JACOBI_NT = 0 / 1 forces the store policy (read per launch: tests switch it)
-int tb_nt(const FsGrid& g)
-{
-    if (const char* e = getenv("FS_JACOBI_NT")) return atoi(e) != 0;
-    return g.jacobi_nt;
-}
-
-int tb_order()
-{
-    static int v = [] {
-        const char* e = getenv("FS_JACOBI_ORDER");
-        return e ? atoi(e) : 1;
-    }();
-    return v;
-}
-
-int tb_chunk_planes()
-{
-    static int v = [] {
-        const char* e = getenv("FS_JACOBI_LZ");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
+// FS_JACOBI_NT = 0 / 1 forces the store policy
+int tb_nt(const FsGrid& g) { return g.env.jacobi_nt >= 0 ? (g.env.jacobi_nt != 0) : g.jacobi_nt; }
 
 template <int KIND, int T, int NTY, int CPT, int AX = 0>
 void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
@@ -434,13 +410,13 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
     }
     A.lz = cdiv(nout, chunks);
     if (g.jacobi_lz > 0) A.lz = min(nout, g.jacobi_lz);
-    if (tb_chunk_planes() > 0) A.lz = min(nout, tb_chunk_planes());
+    if (g.env.jacobi_lz > 0) A.lz = min(nout, g.env.jacobi_lz);
     A.chunks1 = cdiv(n1, A.lz);      // chunks never straddle the two ranges
     chunks = A.chunks1 + cdiv(n2, A.lz);
     A.tiles_x = tiles_x;
     A.tiles_y = tiles_y;
     A.nblocks = A.tiles_x * A.tiles_y * chunks;
-    A.order = tb_order();
+    A.order = g.env.jacobi_order;
     dim3 grid(A.nblocks), block(kW4, NTY);
     if constexpr (KIND == kJacobi && T == kT) {
         if (tb_nt(g)) {
@@ -453,9 +429,10 @@ void launch_tb_cfg(hipStream_t st, const FsGrid& g, TbArgs A)
 
 template <int T, int KIND = kJacobi>
 void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
-               int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo = 0, int zout2_hi = 0)
+               int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo = 0, int zout2_hi = 0, int kpar = 0)
 {
     TbArgs A;
+    A.kpar = kpar & 1;
     ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
     A.p = p - zoff;
     A.np = np - zoff;
@@ -504,11 +481,8 @@ void tune_tb(hipStream_t st, FsGrid& g, int nout, const char* what, Pass&& pass,
     g.jacobi_tile = 0;
     g.jacobi_lz = 0;
     g.jacobi_nt = 0;
-    bool verbose = false;   // FS_JACOBI_TUNE=2 prints the readings
-    if (const char* e = getenv("FS_JACOBI_TUNE")) {
-        if (atoi(e) == 0) return;
-        verbose = atoi(e) == 2;
-    }
+    if (g.env.jacobi_tune == 0) return;
+    const bool verbose = g.env.jacobi_tune == 2;   // FS_JACOBI_TUNE=2 prints the readings
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess) return;
     if (hipEventCreate(&b) != hipSuccess) {
@@ -614,6 +588,7 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
     static std::mutex mu;
     static std::map<std::tuple<int, int, int, int, int>, std::tuple<int, int, int>> tuned;
     std::lock_guard<std::mutex> lock(mu);
+    if (g.env.jacobi_tune == 0) return;   // (and a solver created without the switch still gets its timing)
     const auto key = std::make_tuple(g.nx, g.ny, g.nzl, g.wall_lo, g.wall_hi);
     auto it = tuned.find(key);
     if (it == tuned.end()) {
@@ -662,10 +637,11 @@ bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, con
 
 // Red/black Gauss-Seidel on a dense nx x ny x nz array (rows unpadded): `phases` half-sweeps (2 or 4,
 // red first) from zin into zout; false if this grid cannot take the blocked kernel.
-bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases,
-               bool zin_is_zero)
+bool rbgs_pass(hipStream_t st, const FsEnv& env, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout,
+               int phases, bool zin_is_zero, int kpar)
 {
     FsGrid g{};
+    g.env = env;
     g.nx = nx; g.ny = ny; g.nz = nz;
     g.z0 = 0; g.nzl = nz;
     g.pitch = nx; g.plane = nx * ny;
@@ -681,19 +657,21 @@ bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const f
         std::lock_guard<std::mutex> lock(mu);
         const auto key = std::make_tuple(nx, ny, nz);
         auto it = tuned.find(key);
-        if (it == tuned.end()) {
-            tune_tb(st, g, nz, "rbgs_autotune", [&] { launch_tb<4, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz); });
+        if (it == tuned.end() && env.jacobi_tune != 0) {
+            tune_tb(st, g, nz, "rbgs_autotune", [&] { launch_tb<4, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz, 0, 0, kpar); });
             it = tuned.emplace(key, std::make_pair(g.jacobi_tile, g.jacobi_lz)).first;
         }
-        g.jacobi_tile = it->second.first;
-        g.jacobi_lz = it->second.second;
+        if (it != tuned.end()) {
+            g.jacobi_tile = it->second.first;
+            g.jacobi_lz = it->second.second;
+        }
     }
     if (zin_is_zero) {
-        if (phases == 4) launch_tb<4, kRbgsZero>(st, g, zin, zout, rhs, 0, nz, 0, nz);
-        else launch_tb<2, kRbgsZero>(st, g, zin, zout, rhs, 0, nz, 0, nz);
+        if (phases == 4) launch_tb<4, kRbgsZero>(st, g, zin, zout, rhs, 0, nz, 0, nz, 0, 0, kpar);
+        else launch_tb<2, kRbgsZero>(st, g, zin, zout, rhs, 0, nz, 0, nz, 0, 0, kpar);
     } else {
-        if (phases == 4) launch_tb<4, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz);
-        else launch_tb<2, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz);
+        if (phases == 4) launch_tb<4, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz, 0, 0, kpar);
+        else launch_tb<2, kRbgs>(st, g, zin, zout, rhs, 0, nz, 0, nz, 0, 0, kpar);
     }
     return true;
 }

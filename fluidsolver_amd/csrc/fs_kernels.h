@@ -12,6 +12,29 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Environment switches of the kernels' launchers (experiments and tests; the defaults are the
+// measured best).  Read once per solver, at creation (fsk::read_env), never per launch.
+struct FsEnv {
+    int jacobi_cfg = -1;          // FS_JACOBI_CFG    tile variant 0..3 of the blocked Jacobi kernel, -1 = timed / by rule
+    int jacobi_nt = -1;           // FS_JACOBI_NT     1 / 0 force / forbid non-temporal stores, -1 = timed
+    int jacobi_order = 1;         // FS_JACOBI_ORDER  1 = XCD-contiguous workgroup order
+    int jacobi_lz = 0;            // FS_JACOBI_LZ     planes per z chunk, 0 = timed / cost model
+    int jacobi_tune = 1;          // FS_JACOBI_TUNE   0 = no timing at creation, 2 = print the readings
+    int jacobi_deep = -1;         // FS_JACOBI_DEEP   1 / 0 force / forbid the six-sweep passes, -1 = timed
+    int advect_global = 0;        // FS_ADVECT_GLOBAL bit 0 / 1: velocity / scalar advection without LDS bricks
+    int advect_brick = 1;         // FS_ADVECT_BRICK  1 = narrow LDS brick, 0 = wide
+    long mg_tb_min = 128L * 128L; // FS_MG_TB_MIN     smallest plane (cells) smoothed by the blocked kernel
+    int mg_lds_pad = 1;           // FS_MG_LDS_PAD    0 = the older single-workgroup smoother
+    int mg_no_lds = 0;            // FS_MG_NO_LDS     1 = small levels one launch per colour
+    int mg_slab_ghost = 0;        // FS_MG_SLAB_GHOST cap on the ghost depth of a slab's multigrid levels, 0 = none
+    int vort_lattice = 1;         // FS_VORT_LATTICE  0 = every confined face evaluates its own |omega|
+    int slab_pghost = 8;          // FS_SLAB_PGHOST   4 = one exchange per fused Jacobi pass
+    int xchg_streams = -1;        // FS_XCHG_STREAMS  1 / 0 force the two-stream / one-stream ordering
+    int xchg_debug = 0;           // FS_DEBUG_XCHG
+    int xchg_host_wait = -1;      // FS_XCHG_HOST_WAIT
+    int xchg_timeout_ms = 60000;  // FS_XCHG_TIMEOUT_MS
+};
+
 struct FsGrid {
     int nx, ny, nz;   // global cell counts
     int z0;           // global index of the first owned cell plane
@@ -26,6 +49,7 @@ struct FsGrid {
     int jacobi_tile;  // 1 + tile variant of the blocked Jacobi kernel chosen for this grid, 0 = by rule
     int jacobi_lz;    // planes per z chunk of a blocked pass chosen for this grid, 0 = by the cost model
     int jacobi_nt;    // 1 = the blocked Jacobi passes of this grid store with the non-temporal policy
+    FsEnv env;        // the environment switches as they stood when the solver was created
 };
 
 struct FsFields {
@@ -39,6 +63,8 @@ struct FsSource {
 };
 
 namespace fsk {
+
+FsEnv read_env();   // the FS_* switches of the process environment
 
 // contiguous float ranges copied by one launch (either side may be pinned host memory)
 constexpr int kCopyBatchMax = 10;
@@ -151,16 +177,17 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
 // window plane of the lower children of the first of them), prolongation over every fine plane whose
 // parent the coarse window holds (f0 / c0 = global index of the fine / coarse window's plane 0).
 void mgs_smooth_phase(hipStream_t st, const float* r, float* z, int nx, int ny, int held, int phase, int kpar);
-bool mgs_smooth_pass(hipStream_t st, const float* r, const float* z, float* zalt, int nx, int ny, int held, int colours,
-                     bool z_is_zero);
+bool mgs_smooth_pass(hipStream_t st, const FsEnv& env, const float* r, const float* z, float* zalt, int nx, int ny,
+                     int held, int colours, bool z_is_zero, int kpar);
 void mgs_restrict(hipStream_t st, const float* rf, const float* zf, int nx, int ny, int held_f, int fk0,
                   float* rc_owned, int cz);
 void mgs_prolongate(hipStream_t st, float* zf, int nx, int ny, int held_f, int f0, const float* zc, int c0, int cheld);
 // `phases` (2 or 4) red/black Gauss-Seidel half-sweeps of the zero-outside operator on a dense
 // nx x ny x nz array in one blocked pass, zin -> zout; false if the grid cannot take it
-// (zin_is_zero: zin holds zeros and is not read)
-bool rbgs_pass(hipStream_t st, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout, int phases,
-               bool zin_is_zero = false);
+// (zin_is_zero: zin holds zeros and is not read; kpar: parity of the global z index of plane 0, which
+//  enters the colour of a cell -- a slab's window need not start on an even plane)
+bool rbgs_pass(hipStream_t st, const FsEnv& env, int nx, int ny, int nz, const float* rhs, const float* zin, float* zout,
+               int phases, bool zin_is_zero = false, int kpar = 0);
 // Vorticity confinement.  The three vorticity arrays are dense, vort_elems(g) floats each, zero-filled
 // once by the owner; on a slab they are this rank's window of the global flat index space: its
 // cells plus vort_halo_planes(g) planes of nx*ny entries per side, which the neighbours fill.

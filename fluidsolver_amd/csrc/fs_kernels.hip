@@ -13,6 +13,7 @@
 #include "fs_kernels.h"
 
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 
 #pragma clang fp contract(off)
@@ -375,6 +376,33 @@ void residual(hipStream_t st, const FsGrid& g, const float* p, const float* div,
                        div - zoff, partial, g.nx, g.ny, g.nz, g.pitch, g.plane, g.z0);
     hipLaunchKernelGGL(k_residual_final, dim3(1), dim3(kResBlock), 0, st, partial,
                        residual_partials(g), out);
+}
+
+FsEnv read_env()
+{
+    FsEnv v;
+    auto geti = [](const char* name, int& out) {
+        if (const char* e = getenv(name)) out = atoi(e);
+    };
+    geti("FS_JACOBI_CFG", v.jacobi_cfg);
+    geti("FS_JACOBI_NT", v.jacobi_nt);
+    geti("FS_JACOBI_ORDER", v.jacobi_order);
+    geti("FS_JACOBI_LZ", v.jacobi_lz);
+    geti("FS_JACOBI_TUNE", v.jacobi_tune);
+    geti("FS_JACOBI_DEEP", v.jacobi_deep);
+    geti("FS_ADVECT_GLOBAL", v.advect_global);
+    geti("FS_ADVECT_BRICK", v.advect_brick);
+    if (const char* e = getenv("FS_MG_TB_MIN")) v.mg_tb_min = atol(e);
+    geti("FS_MG_LDS_PAD", v.mg_lds_pad);
+    geti("FS_MG_NO_LDS", v.mg_no_lds);
+    geti("FS_MG_SLAB_GHOST", v.mg_slab_ghost);
+    geti("FS_VORT_LATTICE", v.vort_lattice);
+    geti("FS_SLAB_PGHOST", v.slab_pghost);
+    geti("FS_XCHG_STREAMS", v.xchg_streams);
+    geti("FS_DEBUG_XCHG", v.xchg_debug);
+    geti("FS_XCHG_HOST_WAIT", v.xchg_host_wait);
+    geti("FS_XCHG_TIMEOUT_MS", v.xchg_timeout_ms);
+    return v;
 }
 
 }  // namespace fsk

@@ -1,4 +1,5 @@
-// fs_mgpcg.hip -- multigrid-preconditioned conjugate gradient pressure solve (optional, single GPU).
+// fs_mgpcg.hip -- kernels and launchers of the multigrid-preconditioned conjugate gradient pressure
+// solve (optional): the single-domain V-cycle and the per-window operations of a z-slab.
 //
 // Reference: CuSolver/Source/Solver.cu Conjugate :1226-1297, MG_Preconditioner :1312-1366,
 // Smooth :848-860, SubRestrict/Restrict :822-834, 862-877, Prolongate :836-846, ComputeAp
@@ -13,8 +14,9 @@
 //   * dot products: the reference's Mul + Reduce tree drops elements at most sizes and races
 //     (Solver.cu:241-271, 1212-1224).  Here a dot product is the sum of the binary32 products,
 //     accumulated in binary64 in a fixed order and narrowed to the float the host logic uses.
-//   * z and the coarse levels of r are cleared completely before a V-cycle (the reference clears
-//     mg_space/1024 whole blocks).
+//   * every cell of z and of the coarse levels of r starts a V-cycle from zero: the restriction
+//     starts its sums at zero and the first colour of a level writes both colours, so there are no
+//     clearing passes (the reference clears mg_space/1024 whole blocks, not all of them).
 #include "fs_kernels.h"
 
 #include <cstdint>
@@ -269,7 +271,7 @@ __global__ void k_prolongate(float* __restrict__ z, const float* __restrict__ zc
 // as one dense array that the kernels above treat as a whole grid: beyond the array they read zero,
 // which is the operator's boundary value at a global wall and a wrong value at a slab face.  That
 // error enters the outermost ghost plane and moves one plane inward per stencil application; the
-// driver (fs_solver.hip) refreshes the ghost planes before it can reach an owned plane.
+// driver (fs_project_mgpcg.hip) refreshes the ghost planes before it can reach an owned plane.
 
 // Restriction (the eight SubRestrict launches, as k_restrict) into the OWNED planes of the coarse
 // window: fine plane fk0 + 2*ck holds the lower children of owned coarse plane ck.
@@ -648,23 +650,8 @@ void cg_dot(hipStream_t st, const FsGrid& g, const float* a, const float* b, dou
 // Smallest plane (cells) whose smoothing goes through the temporally blocked kernel; below it a
 // pass of that kernel has too few workgroups to beat four plain launches.  FS_MG_TB_MIN overrides
 // (0 = every level the kernel can take, a huge value = never).
-static long mg_tb_min_plane()
-{
-    if (const char* e = getenv("FS_MG_TB_MIN")) return atol(e);   // read per call: tests switch it
-    return 128L * 128L;
-}
-
-static bool mg_pad_smoother()
-{
-    const char* e = getenv("FS_MG_LDS_PAD");
-    return !e || atoi(e) != 0;
-}
-
-static bool mg_no_lds_smoother()
-{
-    const char* e = getenv("FS_MG_NO_LDS");   // tests: force the per-colour launches on small levels
-    return e && atoi(e) != 0;
-}
+// (FsEnv::mg_tb_min; FS_MG_LDS_PAD=0 selects the older single-workgroup smoother, FS_MG_NO_LDS=1
+// forces the per-colour launches on small levels: tests)
 
 // One V-cycle (Solver.cu:1312-1366): M^-1 r, level 0 of r is the input.  The smoother ping-pongs
 // between z and zalt where it runs blocked, so the result is in either: the return value says
@@ -673,7 +660,8 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
                        int init_smooth_steps, int bottom_smooth_steps)
 {
     // (the coarse levels of r need no clearing: the restriction writes every cell of them)
-    const long tb_min = mg_tb_min_plane();
+    const long tb_min = g.env.mg_tb_min;
+    const bool no_lds = g.env.mg_no_lds != 0, pad = g.env.mg_lds_pad != 0;
     constexpr int kMaxLevels = 16;
     float* cur[kMaxLevels];      // array holding the current z of a level
     float* alt[kMaxLevels];
@@ -687,7 +675,7 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
         if ((long)d.x * d.y >= tb_min) {
             while (phases >= 2) {
                 const int take = phases >= 4 ? 4 : 2;
-                if (!rbgs_pass(st, d.x, d.y, d.z, r + offset, cur[l], alt[l], take, from_zero)) break;
+                if (!rbgs_pass(st, g.env, d.x, d.y, d.z, r + offset, cur[l], alt[l], take, from_zero)) break;
                 float* t = cur[l]; cur[l] = alt[l]; alt[l] = t;
                 phases -= take;
                 from_zero = false;
@@ -695,11 +683,11 @@ float* mg_precondition(hipStream_t st, const FsGrid& g, float* r, float* z, floa
         }
         // levels up to 16384 cells: every colour in one workgroup (FS_MG_LDS_PAD=0: up to 8192 cells,
         // through the older kernel)
-        if (phases > 0 && !mg_no_lds_smoother() && mg_pad_smoother() &&
+        if (phases > 0 && !no_lds && pad &&
             smooth_pad(st, r + offset, cur[l], phases, from_zero, d))
             return;
         const dim3 cgrid(cdiv(cdiv(d.x, 2), 32), cdiv(d.y, 4), d.z), cblock(32, 4);
-        if (phases > 0 && (size_t)d.x * d.y * d.z <= (size_t)kSmoothLdsCells && !mg_no_lds_smoother()) {
+        if (phases > 0 && (size_t)d.x * d.y * d.z <= (size_t)kSmoothLdsCells && !no_lds) {
             if (from_zero) (void)hipMemsetAsync(cur[l], 0, (size_t)d.x * d.y * d.z * sizeof(float), st);
             hipLaunchKernelGGL(k_smooth_lds, dim3(1), dim3(kSmoothLdsThreads), 0, st, r + offset, cur[l], phases / 2, d);
             return;
@@ -752,11 +740,11 @@ void mgs_smooth_phase(hipStream_t st, const float* r, float* z, int nx, int ny, 
 
 // `colours` (2 or 4, red first) colours of the window in one blocked pass from z into zalt; false if
 // the level is not one the blocked kernel is used for (nothing launched)
-bool mgs_smooth_pass(hipStream_t st, const float* r, const float* z, float* zalt, int nx, int ny, int held, int colours,
-                     bool z_is_zero)
+bool mgs_smooth_pass(hipStream_t st, const FsEnv& env, const float* r, const float* z, float* zalt, int nx, int ny,
+                     int held, int colours, bool z_is_zero, int kpar)
 {
-    if ((long)nx * ny < mg_tb_min_plane()) return false;
-    return rbgs_pass(st, nx, ny, held, r, z, zalt, colours, z_is_zero);
+    if ((long)nx * ny < env.mg_tb_min) return false;
+    return rbgs_pass(st, env, nx, ny, held, r, z, zalt, colours, z_is_zero, kpar);
 }
 
 void mgs_restrict(hipStream_t st, const float* rf, const float* zf, int nx, int ny, int held_f, int fk0,
