@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: cell-updates/s of the full simulation step on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--iters 80]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--iters 80] [--flow plume|swirl]
 
 One step = source -> buoyancy -> advect (ux, uy, uz, T, rho) -> divergence ->
 `iters` Jacobi sweeps -> pressure-gradient subtraction, on synthetic input (all-zero
@@ -96,13 +96,17 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fluidsolver_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        # the files of the kernels this benchmark launches; the host-side orchestration
-        # (fs_solver.hip) does not change what a launch moves, and the optional stages' kernels
-        # (fs_mgpcg.hip, fs_vort.hip) are not launched by it
-        if name.endswith((".hip", ".h")) and name not in ("fs_solver.hip", "fs_mgpcg.hip", "fs_vort.hip"):
+        # the files of the kernels this benchmark launches; the host-side orchestration does not
+        # change what a launch moves, and the optional stages' kernels (fs_mgpcg.hip, fs_vort.hip)
+        # are not launched by it
+        if name in ("fs_kernels.h", "fs_kernels.hip", "fs_jacobi.hip", "fs_advect.hip"):
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+VALU_CYCLES_PER_INST = 2.0     # one wave-level vector instruction per SIMD every 2 cycles (nominal)
+SIMDS = 1024                   # 256 CUs x 4
 
 
 def load_pmc(kernel, workload):
@@ -132,11 +136,28 @@ def rocprof_kernel_name(stage, cfg, scheme, fused_div, slab):
             "source": "k_source"}.get(stage, stage)
 
 
+def valu_roofline(pmc, ms_per_launch):
+    """`roofline`-shaped entry of a kernel bound by vector-instruction issue: achieved = wave-level
+    VALU instructions of one launch (committed counter pass) / its duration measured now; peak =
+    1024 SIMDs x clock / 2 cycles per instruction, with the clock the chip held in the counter pass
+    (GRBM_GUI_ACTIVE / 8 XCDs / duration of that pass)."""
+    if not pmc or not pmc.get("SQ_INSTS_VALU") or ms_per_launch <= 0:
+        return None
+    clock = pmc.get("clock_ghz") or 2.4
+    achieved = pmc["SQ_INSTS_VALU"] / (ms_per_launch * 1e-3) / 1e9
+    peak = SIMDS * clock / VALU_CYCLES_PER_INST
+    return {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s",
+            "frac": achieved / peak, "clock_ghz": clock,
+            "clock_source": "GRBM_GUI_ACTIVE / 8 / duration of the committed counter pass" if pmc.get("clock_ghz")
+                            else "nominal (no GRBM_GUI_ACTIVE in the committed counter pass)",
+            "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "avg_launch_ms": ms_per_launch}
+
+
 def stage_rooflines(prof, cells, steps, iters, n):
     """Per stage: algorithmic bytes per step / device time per step against the HBM peak, and for
     the gather kernels, whose limiter is instruction issue, the share of the chip's vector-issue
-    rate (1024 SIMDs x one wave instruction per 2 cycles at 2.4 GHz) their committed instruction
-    count amounts to in the time measured now."""
+    rate (1024 SIMDs x one wave instruction per 2 cycles at the clock of the counter pass) their
+    committed instruction count amounts to in the time measured now."""
     out = {}
     for name, (ms, launches) in prof.items():
         if ms <= 0 or name not in BYTES_PER_CELL:
@@ -156,7 +177,9 @@ def stage_rooflines(prof, cells, steps, iters, n):
             e["limiter"] = "valu issue"
             if pmc and not stale and pmc.get("SQ_INSTS_VALU"):
                 # one launch per step: instructions per launch = per step
-                e["valu_issue_frac"] = pmc["SQ_INSTS_VALU"] / (ms / steps * 1e-3) / (1024 * 2.4e9 / 2.0)
+                v = valu_roofline(pmc, ms / steps)
+                e["valu_issue_frac"] = v["frac"]
+                e["valu_clock_ghz"] = v["clock_ghz"]
                 e["valu_insts_per_cell"] = pmc["SQ_INSTS_VALU"] * 64.0 / cells
         out[name] = e
     return out
@@ -182,43 +205,86 @@ def launch_ranks(n, argv):
 ABANDONED = []   # solvers whose transport failed: kept alive, never destroyed (see main)
 
 
-def open_slab_solver(make, p, rank, world, want, warmup, all_min):
-    """(solver, transport, warm-up steps left) for one rank of a z-slab run.  `make(p, rank, world,
-    transport=...)` builds a solver, `all_min(int)` is the minimum over the ranks.  RCCL is tried
-    first when asked for; every rank must end up on the same transport, so each decision is taken
-    on the minimum over all ranks of "it worked here"."""
-    solver, transport = None, want
-    if transport == "rccl":
-        ok = 1
+# Transports of a z-slab run, tried in this order until one initialises and completes a step on
+# every rank: RCCL with the production ordering; RCCL with the host, not the compute stream, waiting
+# for received planes; RCCL with every transfer on the compute stream (no overlap); halos through
+# host buffers and gloo.  (transport, environment switches read at solver creation, label)
+TIERS = (
+    ("rccl", {}, "RCCL send/recv on a communication stream"),
+    ("rccl", {"FS_XCHG_HOST_WAIT": "1"}, "RCCL send/recv on a communication stream, host-side wait for received planes"),
+    ("rccl", {"FS_XCHG_STREAMS": "0"}, "RCCL send/recv on the compute stream (no overlap)"),
+    ("host", {}, "host buffers + gloo"),
+)
+
+
+def open_slab_solver(make, p, rank, world, want, warmup, all_min, environ=os.environ):
+    """(solver, tier index, warm-up steps left) for one rank of a z-slab run.  `make(p, rank, world,
+    transport=...)` builds a solver, `all_min(int)` is the minimum over the ranks.  Every rank must
+    end up on the same tier, so each decision is taken on the minimum over all ranks of "it worked
+    here".  A tier whose solver cannot be created, or whose first step (the first warm-up step,
+    which doubles as the trial: a transfer that does not complete is reported by the library after
+    FS_XCHG_TIMEOUT_MS instead of hanging) fails on any rank, is given up for the next one, so that
+    the run still yields a number -- with RCCL as long as any ordering of it works."""
+    first = 0 if want == "rccl" else len(TIERS) - 1
+    for tier in range(first, len(TIERS)):
+        transport, env, label = TIERS[tier]
+        last = tier == len(TIERS) - 1
+        saved = {k: environ.get(k) for k in env}
+        environ.update(env)
+        solver, ok = None, 1
         try:
-            solver = make(p, rank, world, transport="rccl").Initialize()
+            solver = make(p, rank, world, transport=transport).Initialize()
         except Exception as e:   # noqa: BLE001
-            print("bench.py rank %d: RCCL transport unavailable (%s)" % (rank, e), file=sys.stderr)
+            if last:
+                raise
+            print("bench.py rank %d: %s unavailable (%s)" % (rank, label, e), file=sys.stderr)
             ok = 0
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    environ.pop(k, None)
+                else:
+                    environ[k] = v
+        if last:
+            return solver, tier, warmup
         if all_min(ok) == 0:
             if solver is not None:
                 solver.close()
-            solver, transport = None, "host"
-    if solver is not None and transport == "rccl" and warmup > 0:
-        # the first warm-up step doubles as a trial of the transport: a transfer that does not
-        # complete is reported by the library after FS_XCHG_TIMEOUT_MS instead of hanging, and
-        # then every rank goes on with host-staged halos, so that the run still yields a number
-        ok = 1
+            continue
+        if warmup <= 0:
+            return solver, tier, warmup
         try:
             solver.step(1)
             solver.sync()
         except Exception as e:   # noqa: BLE001
-            print("bench.py rank %d: RCCL transport failed in the first step (%s)" % (rank, e), file=sys.stderr)
+            print("bench.py rank %d: %s failed in the first step (%s)" % (rank, label, e), file=sys.stderr)
             ok = 0
-        if all_min(ok) == 0:
-            # not closed: destroying a communicator with a transfer stuck in it may block
-            ABANDONED.append(solver)
-            solver, transport = None, "host"
-        else:
-            warmup -= 1
-    if solver is None:
-        solver = make(p, rank, world, transport="host").Initialize()
-    return solver, transport, warmup
+        if all_min(ok) == 1:
+            return solver, tier, warmup - 1
+        # not closed: destroying a communicator with a transfer stuck in it may block
+        ABANDONED.append(solver)
+    raise AssertionError("unreachable")
+
+
+def swirl_fields(n, seed=5):
+    """A developed flow for timing the advection off its fast path: a smooth swirl with |u| dt of
+    1-2 cells that is non-zero everywhere and crosses every wall, random density and temperature.
+    Dense (z, y, x) float32 arrays keyed by field id."""
+    import numpy as np
+    amp = 6.25
+    a = np.arange(n + 1, dtype=np.float64)
+    f = 2.0 * np.pi / n
+    sx, cx = np.sin(f * a)[None, None, :], np.cos(f * a)[None, None, :]
+    sy, cy = np.sin(f * a)[None, :, None], np.cos(f * a)[None, :, None]
+    sz, cz = np.sin(f * a)[:, None, None], np.cos(f * a)[:, None, None]
+    rng = np.random.default_rng(seed)
+    return {
+        0: (amp * sy[:, :n] * cz[:n] + 0.3 * amp * cx).astype(np.float32),
+        1: np.ascontiguousarray(np.broadcast_to((amp * sz[:n] * cx[:, :, :n] + 0.5).astype(np.float32), (n, n + 1, n))),
+        2: np.ascontiguousarray(np.broadcast_to((amp * sx[:, :, :n] * cy[:, :n] - 0.25).astype(np.float32), (n + 1, n, n))),
+        3: rng.random((n, n, n), dtype=np.float32),
+        4: rng.standard_normal((n, n, n), dtype=np.float32),
+    }
 
 
 def main():
@@ -240,6 +306,9 @@ def main():
                     help="> 0: convergence mode, sweep in groups of --check-every until sum r^2 (all ranks) "
                          "is below it or --iters sweeps are done")
     ap.add_argument("--check-every", type=int, default=8)
+    ap.add_argument("--flow", choices=("plume", "swirl"), default="plume",
+                    help="plume = BASELINE's workload (zero state + sphere source); swirl = a developed flow uploaded "
+                         "before the warm-up steps (times the advection off its all-lanes-in-brick fast path; N = 1)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -293,7 +362,13 @@ def main():
         solver = fs.Solver(p).Initialize()
         cells_total = n ** 3
         workload = "%d^3 smoke plume, %d Jacobi sweeps/step, MacCormack, 1 GPU" % (n, args.iters)
+        if args.flow == "swirl":
+            for fid, arr in swirl_fields(n).items():
+                solver.upload(fid, arr)
+            workload = ("%d^3 developed swirl (|u| dt up to 1.6 cells, non-zero everywhere) + sphere source, "
+                        "%d Jacobi sweeps/step, MacCormack, 1 GPU" % (n, args.iters))
         par = "1 GPU"
+        tier = None
     else:
         from fluidsolver_amd.slab import SlabSolver
         p = fs.default_params(n, n, nz_total, jacobi_iters=args.iters, scheme=args.scheme,
@@ -304,13 +379,16 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag.item())
 
-        solver, transport, warm_left = open_slab_solver(SlabSolver, p, rank, world, args.transport, args.warmup, all_min)
+        if args.flow != "plume":
+            raise SystemExit("bench.py: --flow swirl is a single-GPU workload")
+        # a transfer that never completes must end its tier well before the driver's patience does
+        os.environ.setdefault("FS_XCHG_TIMEOUT_MS", "20000")
+        solver, tier, warm_left = open_slab_solver(SlabSolver, p, rank, world, args.transport, args.warmup, all_min)
         cells_total = n * n * nz_total
         workload = ("%dx%dx%d %s, %d Jacobi sweeps/step, MacCormack, z-slabs on %d GPUs, "
                     "halos over %s" % (n, n, nz_total,
                                        "weak-scaling column" if args.scaling == "weak" else "strong scaling",
-                                       args.iters, world,
-                                       "RCCL send/recv" if transport == "rccl" else "host buffers + gloo"))
+                                       args.iters, world, TIERS[tier][2]))
         par = "z-slab x%d" % world
 
     def barrier():
@@ -336,12 +414,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = solver.profile_read()
+    halo = solver.halo_wait()
     solver.profile(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        # max over the ranks of the wall time and of the time each rank waited for halos
+        t = torch.tensor([elapsed, halo["host_ms"], halo["device_ms"]], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, halo["host_ms"], halo["device_ms"] = (float(v) for v in t)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -350,16 +430,19 @@ def main():
         # dominant kernel class by device time
         dom = max(prof, key=lambda k: prof[k][0])
         dom_ms, dom_launches = prof[dom]
+        sweeps_per_launch = 1.0
         if dom == "jacobi":
             sweeps_per_launch = sweeps_done / max(dom_launches, 1)
-            algo_bytes = BYTES_PER_CELL["jacobi"] * cells_rank * sweeps_per_launch
+            # what a pass must move once: read p, read div, write p'
+            algo_bytes = BYTES_PER_CELL["jacobi"] * cells_rank
         else:
             # advect_velocity makes 3 launches per step; its bytes are per stage
             algo_bytes = BYTES_PER_CELL.get(dom, 0.0) * cells_rank * args.steps / max(dom_launches, 1)
         avg_launch_s = dom_ms / max(dom_launches, 1) * 1e-3
         achieved = algo_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         pmc, stale = load_pmc(dom, "%d^3" % n)
-        traffic = float(pmc["hbm_bytes_per_launch"]) if pmc and not stale and world == 1 else None
+        usable = pmc and not stale and world == 1 and args.flow == "plume"
+        traffic = float(pmc["hbm_bytes_per_launch"]) if usable else None
         cfg = solver.jacobi_config()
         fused_div = world == 1
         stage_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
@@ -375,34 +458,42 @@ def main():
             "scaling": args.scaling if world > 1 else None,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (zero initial state, sphere source every step, no RNG)",
+            "data": "synthetic (zero initial state, sphere source every step, no RNG)" if args.flow == "plume" else
+                    "synthetic (analytic swirl velocity, seeded random density and temperature, sphere source every step)",
             "config": {"workload": workload, "nx": n, "ny": n, "nz": nz_total,
-                       "jacobi_sweeps": args.iters, "parallelism": par},
-            "step_hbm_frac": step_bytes_per_cell(sweeps_done / args.steps) * cells_rank / (ms_per_step * 1e-3)
-                             / 1e9 / HBM_PEAK_GBS,
+                       "jacobi_sweeps": args.iters, "parallelism": par, "flow": args.flow},
+            # B_step = 144 + 12 K bytes per cell, every sweep credited: > 1 is possible through temporal blocking
+            "step_hbm_frac_credited": step_bytes_per_cell(sweeps_done / args.steps) * cells_rank / (ms_per_step * 1e-3)
+                                      / 1e9 / HBM_PEAK_GBS,
             "stage_ms_per_step": stage_ms,
             # secondary metric: lattice updates per second of the pressure sweeps alone (per GPU)
             "jacobi_lups": (cells_rank * sweeps_done / (prof["jacobi"][0] * 1e-3)) if prof.get("jacobi", (0, 0))[0] > 0 else None,
             "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, sweeps_done / args.steps, n),
             "autotune": {"jacobi_tile_variant": cfg["variant"], "jacobi_tile_rows": cfg["tile_rows"],
                          "jacobi_aligned_rows": cfg["aligned_rows"], "jacobi_planes_per_chunk": cfg["planes_per_chunk"],
-                         "jacobi_nontemporal_stores": cfg["nontemporal_stores"]},
+                         "jacobi_nontemporal_stores": cfg["nontemporal_stores"],
+                         "jacobi_sweeps_per_pass": cfg.get("sweeps_per_pass")},
             "rccl_ranks": solver.comm_ranks if world > 1 else 0,
             "roofline": {
                 "stage": dom,
                 "kernel": rocprof_kernel_name(dom, cfg, args.scheme, fused_div, world > 1),
                 "bound": "hbm",
                 # what holds this kernel back in practice (the gather kernels are bound by vector
-                # instruction issue, not by memory; their HBM fraction is reported all the same)
+                # instruction issue, not by memory: see roofline_secondary)
                 "limiter": "valu issue" if dom.startswith("advect") else "hbm",
-                # algorithmic bytes of one launch / its average duration: a temporally blocked
-                # pass is credited 12 B per cell per SWEEP, so this may exceed the peak ...
+                # bytes one launch must move once (a fused pass of several sweeps: read p, read div,
+                # write p' = 12 B per cell, however many sweeps it fuses) / its average duration
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                # ... while frac_real prices the bytes the fabric actually moved per launch
-                # (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same kernel sources)
+                # every fused sweep credited its own 12 B per cell (the algorithmic figure of a sweep
+                # times the sweeps of the launch): exceeds the peak by construction of the blocking
+                "sweeps_per_launch": sweeps_per_launch,
+                "achieved_credited": achieved * sweeps_per_launch,
+                "frac_credited": achieved * sweeps_per_launch / HBM_PEAK_GBS,
+                # the bytes the fabric actually moved per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE
+                # of the same kernel sources, from the committed counter pass)
                 "traffic": traffic,
                 "frac_real": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_launch_s > 0 else None,
                 "traffic_source": (None if traffic is None else "profiles/pmc_traffic.json (%s)" % pmc.get("source", "?")),
@@ -411,6 +502,21 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
+        # the gather kernel: bound by vector-instruction issue, priced against that
+        av_ms, av_launches = prof.get("advect_velocity", (0.0, 0))
+        apmc, astale = load_pmc("advect_velocity", "%d^3" % n)
+        sec = valu_roofline(apmc if (apmc and not astale and world == 1 and args.flow == "plume") else None,
+                            av_ms / args.steps)
+        if sec:
+            sec["stage"] = "advect_velocity"
+            sec["kernel"] = rocprof_kernel_name("advect_velocity", cfg, args.scheme, fused_div, world > 1)
+            out["roofline_secondary"] = sec
+        if world > 1:
+            out["transport_tier"] = tier
+            out["halo_wait_ms_per_step"] = {"host": halo["host_ms"] / args.steps, "device": halo["device_ms"] / args.steps,
+                                            "note": "max over ranks; host = host time inside blocking exchange calls, "
+                                                    "device = compute stream standing still for received planes"}
+            out["exchanges_per_step"] = halo["exchanges"] / args.steps
         if traffic is None and world == 1:
             out["roofline"]["traffic_note"] = ("no counter pass of these kernel sources is committed"
                                                if stale else "no counter entry for this workload")

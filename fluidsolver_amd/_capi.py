@@ -24,10 +24,10 @@ EXPORTED_SYMBOLS = (
     "fs_default_params", "fs_create", "fs_destroy", "fs_step", "fs_steps", "fs_sync", "fs_frame", "fs_step_graphs",
     "fs_stage_source", "fs_stage_force", "fs_stage_vorticity", "fs_stage_advect", "fs_stage_confine",
     "fs_stage_divergence",
-    "fs_stage_jacobi", "fs_stage_project", "fs_stage_gradient", "fs_density_host",
-    "fs_velocity_host", "fs_field_host", "fs_field_host_begin", "fs_field_host_end", "fs_field_size", "fs_field_upload", "fs_field_device",
+    "fs_stage_jacobi", "fs_stage_project", "fs_stage_pressure_solve", "fs_mg_vcycle", "fs_stage_gradient", "fs_density_host",
+    "fs_velocity_host", "fs_field_host", "fs_field_host_begin", "fs_field_host_end", "fs_field_size", "fs_field_upload", "fs_field_fill", "fs_field_device",
     "fs_residual", "fs_residual_noalloc", "fs_last_sweeps", "fs_cg_residual", "fs_last_error", "fs_version",
-    "fs_profile_enable", "fs_profile_read", "fs_profile_reset",
+    "fs_profile_enable", "fs_profile_read", "fs_profile_reset", "fs_halo_wait",
     "fs_comm_unique_id", "fs_create_slab", "fs_slab_info", "fs_comm_ranks", "fs_jacobi_config",
 )
 
@@ -97,7 +97,8 @@ def load_library():
     L.fs_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     for name in ("fs_destroy", "fs_step", "fs_sync", "fs_frame", "fs_stage_source", "fs_stage_force",
                  "fs_stage_advect", "fs_stage_divergence", "fs_stage_project", "fs_stage_gradient",
-                 "fs_stage_vorticity", "fs_stage_confine", "fs_last_sweeps", "fs_step_graphs"):
+                 "fs_stage_vorticity", "fs_stage_confine", "fs_last_sweeps", "fs_step_graphs",
+                 "fs_stage_pressure_solve", "fs_mg_vcycle"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = C.c_int
     L.fs_steps.argtypes = [vp, C.c_int]
@@ -114,6 +115,7 @@ def load_library():
     L.fs_field_host_end.restype = _fp
     L.fs_field_size.restype = C.c_size_t
     L.fs_field_upload.argtypes = [vp, C.c_int, _fp]
+    L.fs_field_fill.argtypes = [vp, C.c_int, C.c_float]
     L.fs_field_device.argtypes = [vp, C.c_int, C.POINTER(_fp), C.POINTER(Layout)]
     L.fs_residual.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.fs_residual_noalloc.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
@@ -123,6 +125,7 @@ def load_library():
     L.fs_profile_enable.argtypes = [vp, C.c_int]
     L.fs_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.fs_profile_reset.argtypes = [vp]
+    L.fs_halo_wait.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.fs_last_error.restype = C.c_char_p
     L.fs_version.restype = C.c_char_p
     _lib = L
@@ -266,6 +269,9 @@ class Solver:
             raise ValueError("field %d wants shape %s, got %s" % (field, self.local_shape(field), a.shape))
         self._check(self._L.fs_field_upload(self._handle(), field, a.ctypes.data_as(_fp)))
 
+    def fill(self, field, value):
+        self._check(self._L.fs_field_fill(self._handle(), field, value))
+
     def device_field(self, field):
         ptr = _fp()
         lay = Layout()
@@ -293,7 +299,7 @@ class Solver:
 
     @property
     def step_graphs(self):
-        """captured step graphs held (-1: capture failed, eager launches)"""
+        """captured step graphs held"""
         return self._L.fs_step_graphs(self._handle())
 
     @property
@@ -314,6 +320,13 @@ class Solver:
             self._check(self._L.fs_profile_read(self._handle(), q, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+    def halo_wait(self):
+        """{host_ms, device_ms, exchanges} a z-slab spent waiting for halos since the last
+        profile_reset (zeros on one GPU); synchronises."""
+        h, d, n = C.c_double(), C.c_double(), C.c_longlong()
+        self._check(self._L.fs_halo_wait(self._handle(), C.byref(h), C.byref(d), C.byref(n)))
+        return {"host_ms": h.value, "device_ms": d.value, "exchanges": n.value}
 
     @property
     def last_sweeps(self):

@@ -5,6 +5,8 @@
  *
  * Same public names and meaning as the reference class (Solver.h:13-44):
  *   Solver(), ~Solver(), Initialize(), Update(), Advect(), Project(), GetDensityField(),
+ * and the internal steps it happens to declare public (Solver.h:28-42): Scatter(),
+ * ResetGridValue(), Reduce(), Restrict(), Conjugate(), MG_Preconditioner(), PsiVCycle();
  * plus velocity access, which the reference lacks.  The object holds the C-ABI handle of
  * include/fluidsolver.h and a few settings, so constructing it by value on the caller's
  * stack, as the Renderer does, does not depend on the library's internals.
@@ -60,6 +62,32 @@ public:
 	/* the two sub-steps the reference also exposes publicly (Solver.h:24,26) */
 	void Advect();
 	void Project();
+	/* The rest of the reference's public surface (Solver.h:28-42).  Its Renderer calls none of
+	   them (Renderer/Source/FluidSolver.cpp:152-156, 210-213); they are internal steps of
+	   Update() that the reference declares public, and they act on private device arrays, so a
+	   caller can observe them only through later results. */
+	/* empty in the reference (Solver.cu:1195-1202) */
+	void Scatter() {}
+	/* density and velocity back to zero (Solver.cu:1204-1210; never called by the reference) */
+	void ResetGridValue();
+	/* The reference reduces its private `temp` array in place (Solver.cu:1212-1224), a step of
+	   its dot products.  Here every dot product is a fused, deterministic reduction inside the
+	   kernels of the solve, so there is nothing left to do: no-op. */
+	void Reduce() {}
+	/* One restriction step between two levels of the private multigrid arrays (Solver.cu:862-877);
+	   only meaningful inside MG_Preconditioner(), which performs it itself: no-op. */
+	void Restrict(int /*offset*/, int /*max_pos_x*/, int /*max_pos_y*/, int /*max_pos_z*/) {}
+	/* The pressure solve of Project() on the current divergence (Solver.cu:1226-1297).  The
+	   reference's only call passes its own pressure and divergence arrays (Solver.cu:1191), which
+	   are private, so the arguments are ignored and the solver's own fields are used; with
+	   SetMultigridSolver(false) the Jacobi sweeps run instead. */
+	void Conjugate(float* /*res*/ = nullptr, float* /*field*/ = nullptr);
+	/* one V-cycle z = M^-1 r on the private multigrid arrays (Solver.cu:1312-1366); needs the
+	   multigrid solver (the default) */
+	void MG_Preconditioner();
+	/* Stream-function V-cycles of IVOCK (Solver.cu:1299-1310), which the reference compiles out
+	   (IVOCK 0, Solver.cu:14) and this library does not contain: no-op. */
+	void PsiVCycle() {}
 	/* blocking copy of the density field into a solver-owned host buffer of
 	   Nx*Ny*Nz floats, x fastest (Solver.cu:1368-1372); valid until the next call */
 	float* GetDensityField();

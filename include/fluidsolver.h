@@ -178,8 +178,8 @@ FS_API int fs_sync(fs_solver* s);
 FS_API int fs_frame(const fs_solver* s);          /* Solver.h:76 current_frame */
 /* fs_step replays a captured hipGraph per assignment of the buffers where it can (one GPU, fixed
    sweep count, no stage timing; z-slabs launch eagerly).
-   Returns the number of step graphs this solver holds, -1 if a capture failed and the solver went
-   back to eager launches (no counterpart in the reference, which launches eagerly). */
+   Returns the number of step graphs this solver holds (no counterpart in the reference, which
+   launches eagerly). */
 FS_API int fs_step_graphs(const fs_solver* s);
 
 /* -- individual stages, in the order fs_step runs them.  The reference exposes
@@ -193,6 +193,13 @@ FS_API int fs_stage_confine(fs_solver* s);        /* ApplyVortConfinement Solver
 FS_API int fs_stage_divergence(fs_solver* s);     /* DivergenceKernel  Solver.cu:406-423 */
 FS_API int fs_stage_jacobi(fs_solver* s, int sweeps); /* JacobiKernel + swap, Solver.cu:426-443, 1180-1184 */
 FS_API int fs_stage_project(fs_solver* s);        /* Solver::Project   Solver.cu:1168-1189 */
+/* The solve of Project() alone, on the divergence field as it stands: the Jacobi loop
+   (Solver.cu:1180-1184) or Solver::Conjugate(f_pressure, f_div) (Solver.cu:1226-1297, public in
+   Solver.h:37), by fs_params.pressure_solver. */
+FS_API int fs_stage_pressure_solve(fs_solver* s);
+/* Solver::MG_Preconditioner (Solver.cu:1312-1366, public in Solver.h:40): one V-cycle z = M^-1 r on
+   the solver's own multigrid arrays.  FS_PRESSURE_MGPCG solvers only, else FS_ERR_STATE. */
+FS_API int fs_mg_vcycle(fs_solver* s);
 FS_API int fs_stage_gradient(fs_solver* s);       /* ApplyGradientU*   Solver.cu:446-483 */
 
 /* -- buffer access: replaces Solver::GetDensityField (Solver.cu:1368-1372).
@@ -211,6 +218,9 @@ FS_API int fs_field_host_begin(fs_solver* s, int field);
 FS_API const float* fs_field_host_end(fs_solver* s, int field);
 /* Upload a dense host array into a field (tests, restart from a dump). */
 FS_API int fs_field_upload(fs_solver* s, int field, const float* src);
+/* Set every element of a field (this rank's planes) to one value: what Solver::ResetGridValue
+   (Solver.cu:1204-1210, kernels :209-229) does with 0 for the density and the velocity. */
+FS_API int fs_field_fill(fs_solver* s, int field, float value);
 /* Zero-copy access for device-side consumers. *ptr addresses element (0,0,z0).  The pointer is
    valid until the next call that steps or uploads (buffers are swapped); a consumer that writes
    through it must call this function again before the next step so that ghost planes and
@@ -225,9 +235,10 @@ FS_API int fs_field_device(fs_solver* s, int field, float** ptr, fs_layout* layo
       i.e. when the last sweep ran on its own (sweep count not a multiple of 4, or
       FS_FLAG_JACOBI_NAIVE), else FS_ERR_STATE. -- */
 FS_API int fs_residual(fs_solver* s, int which, double* out);
-/* fs_residual for callers that must not allocate device memory (code under HIP graph capture
-   elsewhere in the process, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
-   in the reference.  Same arguments, result and synchronisation as fs_residual, but the partial
+/* fs_residual for callers that must not allocate device or pinned memory (tight serving loops,
+   harnesses that forbid hipMalloc; the call still synchronises its stream like fs_residual, so
+   while another thread captures a HIP graph that thread must capture in thread-local or relaxed
+   mode).  No counterpart in the reference.  Same arguments, result and synchronisation as fs_residual, but the partial
    sums live in a file-scope device array of the library (FS_NOALLOC_MAX_ROWS partials + the total,
    8 MiB per GPU, held until the process ends) instead of the solver's own scratch buffer, and the
    call makes no hipMalloc / hipFree / pinned allocation.  Limits: single-GPU solvers (not z-slabs:
@@ -254,6 +265,13 @@ enum {
 FS_API int fs_profile_enable(fs_solver* s, int on);
 FS_API int fs_profile_read(fs_solver* s, int stage, double* ms_total, long long* launches);
 FS_API int fs_profile_reset(fs_solver* s);
+/* How long a z-slab waited for halos since the last fs_profile_reset (no counterpart in the
+   reference, which is single-GPU): host_ms = host time inside exchange calls that block (the
+   host-staged transport's pack / callback, a host-side wait for received planes); device_ms = time
+   the compute stream stood still between asking for received planes and having them (collected
+   only while stage timing is enabled; synchronises); exchanges = exchanges begun.  Any pointer may
+   be NULL.  All zero on a single-GPU solver. */
+FS_API int fs_halo_wait(fs_solver* s, double* host_ms, double* device_ms, long long* exchanges);
 
 FS_API const char* fs_last_error(void);
 FS_API const char* fs_version(void);

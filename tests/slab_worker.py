@@ -193,6 +193,9 @@ def main():
         kw["flags"] = kw.get("flags", 0) | fs.FS_FLAG_VORT_CONFINE
     if "mgpcg" in extra:
         kw["pressure_solver"] = fs.FS_PRESSURE_MGPCG
+    for e in extra:
+        if e.startswith("mglevel="):
+            kw["mg_level"] = int(e.split("=")[1])
     p = fs.default_params(nx, ny, nz, device=dev, **kw)
     s = SlabSolver(p, rank, world, transport=mode).Initialize()
     okw = {a: b for a, b in kw.items() if a not in ("flags", "tolerance", "check_every", "max_sweeps")}

@@ -52,22 +52,34 @@ def test_counter_summary_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     assert bench.load_pmc("jacobi", "512^3") == (entry, True)
 
 
+ENV = {}     # the environment open_slab_solver edits (a stand-in for os.environ)
+
+
+def _tier_of(transport):
+    if transport == "host":
+        return 3
+    return 1 if ENV.get("FS_XCHG_HOST_WAIT") == "1" else 2 if ENV.get("FS_XCHG_STREAMS") == "0" else 0
+
+
 class _FakeSolver:
-    """Stand-in for SlabSolver: `plan` says which transports fail to initialise or to step."""
+    """Stand-in for SlabSolver: `plan` says which tiers fail to initialise or to step.  Like the
+    library, it reads the environment switches when it is created."""
     plan = {}
     made = []
 
     def __init__(self, p, rank, world, transport):
         self.transport, self.steps, self.closed = transport, 0, False
+        self.tier = None
         _FakeSolver.made.append(self)
 
     def Initialize(self):
-        if _FakeSolver.plan.get(self.transport) == "init":
+        self.tier = _tier_of(self.transport)
+        if _FakeSolver.plan.get(self.tier) == "init":
             raise RuntimeError("no such transport here")
         return self
 
     def step(self, n=1):
-        if _FakeSolver.plan.get(self.transport) == "step":
+        if _FakeSolver.plan.get(self.tier) == "step":
             raise RuntimeError("the transfer did not finish")
         self.steps += n
 
@@ -78,27 +90,48 @@ class _FakeSolver:
         self.closed = True
 
 
-@pytest.mark.parametrize("plan,want,transport,warm_left,abandoned", [
-    ({}, "rccl", "rccl", 2, 0),                       # the trial step is the first warm-up step
-    ({"rccl": "init"}, "rccl", "host", 3, 0),         # RCCL cannot be set up: host-staged halos
-    ({"rccl": "step"}, "rccl", "host", 3, 1),         # a transfer times out: abandoned, never closed
-    ({}, "host", "host", 3, 0),
+@pytest.mark.parametrize("plan,want,tier,warm_left,abandoned", [
+    ({}, "rccl", 0, 2, 0),                               # the trial step is the first warm-up step
+    ({0: "init", 1: "init", 2: "init"}, "rccl", 3, 3, 0),   # RCCL cannot be set up at all: host-staged halos
+    ({0: "step"}, "rccl", 1, 2, 1),                      # the GPU-side wait stalls: RCCL with the host waiting
+    ({0: "step", 1: "step"}, "rccl", 2, 2, 2),           # ... then RCCL on the compute stream alone
+    ({0: "step", 1: "step", 2: "step"}, "rccl", 3, 3, 3),   # ... and only then host buffers + gloo
+    ({}, "host", 3, 3, 0),
 ])
-def test_bench_transport_selection(plan, want, transport, warm_left, abandoned, monkeypatch):
+def test_bench_transport_selection(plan, want, tier, warm_left, abandoned, monkeypatch):
+    """The tiers of a multi-rank run: three orderings of the RCCL transport before the host-staged
+    fallback; the switches of a tier are set while its solver is created and restored afterwards;
+    a solver whose transfer stalled is abandoned, never closed."""
+    sys.path.insert(0, ROOT)
     import bench
     monkeypatch.setattr(bench, "ABANDONED", [])
+    ENV.clear()
+    ENV["FS_XCHG_STREAMS"] = "keep"       # a value the caller had set comes back after a tier that overrides it
     _FakeSolver.plan, _FakeSolver.made = plan, []
-    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, want, 3, lambda v: v)
-    assert (t, w, len(bench.ABANDONED)) == (transport, warm_left, abandoned)
-    assert s.transport == transport and not s.closed
+    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, want, 3, lambda v: v, environ=ENV)
+    assert (t, w, len(bench.ABANDONED)) == (tier, warm_left, abandoned)
+    assert s.tier == tier and not s.closed and s.transport == bench.TIERS[tier][0]
+    assert ENV == {"FS_XCHG_STREAMS": "keep"}
     for other in _FakeSolver.made:
         assert other is s or not other.closed      # failed to initialise, or abandoned: never closed
-    # RCCL fine here but not on another rank: this rank's RCCL solver is closed, all use the host transport
+    # RCCL fine here but not on another rank: this rank's RCCL solvers are closed, all use the host transport
+    ENV.clear()
     _FakeSolver.plan, _FakeSolver.made = {}, []
-    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, "rccl", 3, lambda v: 0)
+    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, "rccl", 3, lambda v: 0, environ=ENV)
     if want == "rccl":
-        assert t == "host" and _FakeSolver.made[0].closed and s is _FakeSolver.made[1]
+        assert t == 3 and all(m.closed for m in _FakeSolver.made[:3]) and s is _FakeSolver.made[3]
     # without warm-up steps there is no trial
-    _FakeSolver.plan, _FakeSolver.made = {"rccl": "step"}, []
-    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, "rccl", 0, lambda v: v)
-    assert (t, w) == ("rccl", 0)
+    _FakeSolver.plan, _FakeSolver.made = {0: "step"}, []
+    s, t, w = bench.open_slab_solver(_FakeSolver, None, 0, 2, "rccl", 0, lambda v: v, environ=ENV)
+    assert (t, w) == (0, 0)
+
+
+def test_swirl_flow_is_developed_everywhere():
+    sys.path.insert(0, ROOT)
+    import bench
+    import numpy as np
+    f = bench.swirl_fields(24)
+    assert f[0].shape == (24, 24, 25) and f[1].shape == (24, 25, 24) and f[2].shape == (25, 24, 24)
+    speed = np.sqrt(f[0][:, :, :24] ** 2 + f[1][:, :24, :] ** 2 + f[2][:24] ** 2)
+    assert 0.2 * speed.max() <= 8.0 and 1.0 <= 0.2 * speed.max()        # |u| dt of 1-2 cells at its fastest
+    assert (speed > 0.05).mean() > 0.99

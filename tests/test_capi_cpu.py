@@ -81,6 +81,33 @@ def test_renderer_compiles_against_our_solver_header():
         assert r.returncode == 0, r.stdout[-2000:]
 
 
+def test_solver_header_mirrors_the_reference_public_class(tmp_path):
+    """Every public member function the reference class declares (CuSolver/Include/Solver.h:16-44)
+    exists in include/Solver.h with a compatible signature: a translation unit that calls each of
+    them compiles and links against libCuSolver.so."""
+    calls = {"Initialize": "s.Initialize();", "Update": "s.Update();", "Advect": "s.Advect();",
+             "Project": "s.Project();", "Scatter": "s.Scatter();", "ResetGridValue": "s.ResetGridValue();",
+             "Reduce": "s.Reduce();", "Restrict": "s.Restrict(0, Nx, Ny, Nz);",
+             "Conjugate": "s.Conjugate((float*)0, (float*)0);", "MG_Preconditioner": "s.MG_Preconditioner();",
+             "PsiVCycle": "s.PsiVCycle();", "GetDensityField": "float* rho = s.GetDensityField(); (void)rho;"}
+    ref_header = os.path.join(REF, "CuSolver", "Include", "Solver.h")
+    if os.path.exists(ref_header):
+        text = open(ref_header).read()
+        public = text[text.index("public:"):text.index("private:")]
+        names = set(re.findall(r"\b(?:void|float\*)\s+(\w+)\s*\(", public))
+        assert names == set(calls), names ^ set(calls)
+    src = tmp_path / "surface.cpp"
+    src.write_text("#include <Solver.h>\nint main(int argc, char**) {\n  Solver s = Solver();\n  if (argc > 100) {\n    "
+                   + "\n    ".join(calls.values()) + "\n  }\n  return 0;\n}\n")
+    lib = os.path.join(ROOT, "fluidsolver_amd", "lib")
+    if shutil.which("g++") is None or not os.path.exists(os.path.join(lib, "libCuSolver.so")):
+        pytest.skip("g++ or the built shim absent")
+    r = subprocess.run(["g++", "-std=c++14", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                        str(tmp_path / "surface"), "-L", lib, "-lCuSolver", "-lfluidsolver", "-Wl,-rpath," + lib],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+
+
 @pytest.mark.skipif(shutil.which("cmake") is None, reason="cmake absent")
 def test_linux_cmake_build_of_the_solver_consumers(tmp_path):
     """integration/CMakeLists.txt (the Linux stand-in for the reference's top-level CMakeLists.txt:

@@ -515,19 +515,112 @@ def test_headless_program_through_the_solver_class(fs, mode):
     s.close()
 
 
-def test_asynchronous_read_back_is_a_snapshot(fs):
-    """fs_field_host_begin/_end: the returned field is the one at the time of _begin even though
-    more steps were enqueued before _end."""
-    s = fs.Solver(fs.default_params(48, 40, 32, jacobi_iters=8)).Initialize()
+def test_asynchronous_read_back_is_a_snapshot(fs, oracle):
+    """fs_field_host_begin/_end (what replaces the blocking copy of Solver::GetDensityField,
+    Solver.cu:1368-1372): the returned field is the one at the time of _begin even though more
+    steps were enqueued before _end, and it is the oracle's density at that step."""
+    s, o = make_pair(fs, oracle, 48, 40, 32, jacobi_iters=8)
     s.step(3)
+    o.step(3)
     want = s.field(fs.FS_RHO)
     s.field_begin(fs.FS_RHO)
     s.step(4)
     got = s.field_end(fs.FS_RHO)
     assert np.array_equal(got, want)
+    assert np.array_equal(got, o.get(oracle.RHO)) and got.any()
+    o.close()
     assert not np.array_equal(s.field(fs.FS_RHO), want)
     with pytest.raises(fs.FsError):
         s.field_end(fs.FS_RHO)
     s.field_begin(fs.FS_UZ)
     assert np.array_equal(s.field_end(fs.FS_UZ), s.field(fs.FS_UZ))
     s.close()
+
+
+@pytest.mark.parametrize("field", [3, 1, 2])   # rho, uy (ny + 1 rows), uz (nz + 1 planes)
+def test_device_pointer_read_from_a_second_stream(fs, oracle, field):
+    """fs_field_device (the zero-copy hand-off that replaces the host round trip of
+    Solver::GetDensityField, Solver.cu:1368-1372, for a device-side consumer): after fs_sync a
+    consumer reads the field through the raw pointer and the layout on a stream of its own, and
+    finds the oracle's values."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    nx, ny, nz = 40, 36, 28
+    s, o = make_pair(fs, oracle, nx, ny, nz, jacobi_iters=8)
+    s.step(3)
+    o.step(3)
+    s.sync()
+    ptr, lay = s.device_field(field)
+    assert (lay.dx, lay.dy, lay.dz) == (nx, ny + (field == 1), nz + (field == 2)) and lay.z0 == 0
+    rows = lay.plane // lay.pitch
+    n = lay.nz_local * lay.plane
+    host = np.full(n, np.nan, np.float32)
+    stream = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    assert hip.hipMemcpyAsync(host.ctypes.data, ptr, n * 4, 2, stream) == 0     # 2 = device to host
+    assert hip.hipStreamSynchronize(stream) == 0
+    assert hip.hipStreamDestroy(stream) == 0
+    got = host.reshape(lay.nz_local, rows, lay.pitch)[:, :lay.dy, :lay.dx]
+    want = o.get(field)
+    assert got.shape == want.shape and np.array_equal(got, want) and want.any()
+    # everything outside the field's own extent is zero (what the zero-outside gathers rely on)
+    pad = host.reshape(lay.nz_local, rows, lay.pitch).copy()
+    pad[:, :lay.dy, :lay.dx] = 0
+    assert not pad.any()
+    s.close(); o.close()
+
+
+def test_pressure_solve_vcycle_and_fill_entry_points(fs, oracle):
+    """The entry points behind the rest of the reference's public class (Solver.h:28-42):
+    fs_stage_pressure_solve = the solve of Project() without the divergence (Conjugate / the Jacobi
+    loop), fs_mg_vcycle = MG_Preconditioner on the private arrays (state-checked, no visible effect
+    on the following solve), fs_field_fill = ResetGridValue's kernels."""
+    nx, ny, nz = 32, 24, 16
+    for solver in (fs.FS_PRESSURE_JACOBI, fs.FS_PRESSURE_MGPCG):
+        g, o = make_pair(fs, oracle, nx, ny, nz, jacobi_iters=12, pressure_solver=solver)
+        st = random_fields(nx, ny, nz, seed=77, vel_scale=1.0)
+        load_state(g, o, st)
+        for _ in range(2):       # (the first MGPCG solve does not reach the pressure field, Solver.cu:1295)
+            g.stage("divergence")
+            if solver == fs.FS_PRESSURE_MGPCG:
+                g._check(g._L.fs_mg_vcycle(g._handle()))
+            g.stage("pressure_solve")
+            o.stage("project")
+        if solver == fs.FS_PRESSURE_JACOBI:
+            assert g._L.fs_mg_vcycle(g._handle()) == -6
+            assert np.array_equal(g.field(fs.FS_P), o.get(oracle.P))
+        else:
+            assert g.cg_info()[0] == o.cg_info()[0]
+            assert rel_linf(g.field(fs.FS_P), o.get(oracle.P)) <= 1e-5
+        g.fill(fs.FS_RHO, 0.0)
+        g.fill(fs.FS_UX, 0.25)
+        assert not g.field(fs.FS_RHO).any()
+        assert np.array_equal(g.field(fs.FS_UX), np.full((nz, ny, nx + 1), 0.25, np.float32))
+        # the rows and planes beyond the field stay zero: a step from the filled state matches the oracle
+        o.set(oracle.RHO, np.zeros((nz, ny, nx), np.float32))
+        o.set(oracle.UX, np.full((nz, ny, nx + 1), 0.25, np.float32))
+        g.step(); o.step()
+        for f in range(5):
+            if solver == fs.FS_PRESSURE_JACOBI:
+                assert np.array_equal(g.field(f), o.get(f)), f
+            else:
+                assert rel_linf(g.field(f), o.get(f)) <= 1e-5, f
+        g.close(); o.close()
+
+
+def test_headless_program_calls_the_whole_public_class(fs):
+    """fs_headless ... surface: every public method the reference class declares (Solver.h:16-44)
+    is callable on the C++ `Solver`; ResetGridValue leaves density and velocity zero."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fluidsolver_amd", "bin", "fs_headless")
+    for mode in ("shipped", "jacobi"):
+        out = subprocess.run([exe, "3", mode, "surface"], check=True, stdout=subprocess.PIPE, timeout=120, text=True).stdout
+        m = re.search(r"surface: max\(rho\) before reset ([-0-9.e+]+), nonzero after reset (\d)", out)
+        assert m and float(m.group(1)) > 0 and m.group(2) == "0", out

@@ -2,7 +2,7 @@
 
 No GPU here, so the HIP kernels cannot run; what these tests pin is the decomposition itself --
 which ghost planes are refreshed when, and how wide -- by replaying the library's orchestration
-(fluidsolver_amd/csrc/fs_solver.hip: ensure_advect_ghosts / ensure_velocity_ghosts /
+(fluidsolver_amd/csrc/fs_exchange.hip: ensure_advect_ghosts / ensure_velocity_ghosts /
 run_jacobi's split passes with one exchange of 4 planes after each or, on slabs of 25 planes and more,
 its pairs of passes with one exchange of 8 planes per pair, extended divergence range) with the CPU
 oracle's kernels.  Every rank keeps full-size arrays but only its owned + ghost planes hold data;
@@ -20,7 +20,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-GHOST = 4      # fs_solver.hip: ghost planes of a slab
+GHOST = 4      # fs_solver.hip (create_common): ghost planes of a slab
 BLOCK = 4      # fsk::jacobi_block(): sweeps fused per pass
 
 

@@ -132,6 +132,11 @@ def test_slab_confinement_needs_slabs_as_thick_as_its_reach(fs):
     (3, (32, 16, 96), 2, ["mgpcg"], {"FS_MG_TB_MIN": "0", "FS_MG_SLAB_GHOST": "2"}),
     # one ghost plane: an exchange before every colour
     (2, (16, 16, 32), 2, ["mgpcg"], {"FS_MG_SLAB_GHOST": "1"}),
+    # coarsest slabs of odd thickness (9 and 5 planes) on the blocked path: the upper ranks' windows
+    # start on planes of odd global index, the colour of a cell must follow the global index and the
+    # sequence of exchanges must not depend on it
+    (2, (32, 32, 36), 2, ["mgpcg", "random", "mglevel=2"], {"FS_MG_TB_MIN": "0", "FS_MG_SLAB_GHOST": "4"}),
+    (3, (32, 32, 30), 2, ["mgpcg", "mglevel=2"], {"FS_MG_TB_MIN": "0", "FS_MG_SLAB_GHOST": "3"}),
 ])
 def test_slab_mgpcg(world, dims, steps, extra, env):
     """FS_PRESSURE_MGPCG on slabs: every rank runs the V-cycle and the CG vector operations on its
@@ -198,6 +203,34 @@ def test_host_transport_stream_ordering_with_itself_as_neighbour():
     the compute stream itself waiting for the received planes (FS_XCHG_HOST_WAIT=0, the ordering of
     the RCCL transport): two-stream ordering against one-stream ordering, 12 steps."""
     run_ranks(1, ["selfpeer_host", 64, 48, 24, 12, 20], 29662, {"FS_XCHG_HOST_WAIT": "0"})
+
+
+def _devices():
+    import torch
+    return torch.cuda.device_count()     # (counting devices does not initialise the GPU)
+
+
+RCCL_CASES = [
+    (2, (64, 48, 64), 4, 20, ["random"], {}),                       # 32 planes per rank: paired passes, advection split
+    (2, (36, 28, 24), 3, 7, [], {"FS_SLAB_PGHOST": "4"}),            # one exchange per pass, passes of 4 and 3 sweeps
+    (2, (32, 24, 32), 3, 30, ["mgpcg", "confine"], {}),              # the shipped configuration: windows + all-reduce
+    (2, (24, 24, 24), 3, 0, ["converge"], {}),                       # residual norm over ncclAllReduce
+    (2, (64, 48, 64), 3, 20, ["random"], {"FS_XCHG_HOST_WAIT": "1"}),   # the fall-back orderings of the same transport
+    (2, (64, 48, 64), 3, 20, ["random"], {"FS_XCHG_STREAMS": "0"}),
+    (4, (48, 40, 80), 3, 12, ["random"], {}),                        # interior ranks with two neighbours
+    (8, (64, 64, 256), 2, 16, [], {}),                               # the strong-scaling layout of an 8-GPU node
+]
+
+
+@pytest.mark.parametrize("case", range(len(RCCL_CASES)))
+def test_rccl_between_devices(case):
+    """One rank per GPU, halos over ncclSend/ncclRecv between DISTINCT devices (and the residual
+    norm / MGPCG's dot products over ncclAllReduce), bit for bit against the single-domain oracle.
+    Needs as many GPUs as ranks: skipped on a smaller box."""
+    world, dims, steps, k, extra, env = RCCL_CASES[case]
+    if _devices() < world:
+        pytest.skip("%d GPUs needed, %d visible" % (world, _devices()))
+    run_ranks(world, ["rccl", *dims, steps, k, *extra], 29800 + case, env)
 
 
 def test_single_rank_rccl_communicator():

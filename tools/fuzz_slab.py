@@ -55,9 +55,16 @@ def main():
         mgpcg = rng.random() < 0.3
         if which != "all":
             mgpcg = which == "mgpcg"
+        mg_level = 4
         if mgpcg:
-            nx, ny = (int(8 * rng.integers(1, 7)) for _ in range(2))
-            nz = int(8 * world * rng.integers(1, 5))
+            # every depth of the V-cycle, coarsest slabs of odd and even thickness, the blocked
+            # smoother on every level it can take or on none, every ghost depth of the windows
+            mg_level = int(rng.integers(1, 5))
+            m = 1 << (mg_level - 1)
+            nx, ny = (int(m * rng.integers(1, max(2, 56 // m))) for _ in range(2))
+            nz = int(m * world * rng.integers(1, max(2, 40 // m)))
+            os.environ["FS_MG_TB_MIN"] = str(int(rng.choice([0, 128 * 128])))
+            os.environ["FS_MG_SLAB_GHOST"] = str(int(rng.integers(1, 9)))
         else:
             nx = int(rng.choice([int(rng.integers(1, 40)), int(4 * rng.integers(2, 30))]))
             ny = int(rng.integers(1, 70))
@@ -79,10 +86,12 @@ def main():
             gkw["flags"] = fs.FS_FLAG_VORT_CONFINE
             okw["vort_confine"] = 1
         if mgpcg:
-            gkw["pressure_solver"] = fs.FS_PRESSURE_MGPCG
-            okw["pressure_solver"] = oracle.PRESSURE_MGPCG
+            gkw.update(pressure_solver=fs.FS_PRESSURE_MGPCG, mg_level=mg_level)
+            okw.update(pressure_solver=oracle.PRESSURE_MGPCG, mg_level=mg_level)
         desc = "case %d: %dx%dx%d on %d ranks, scheme %d k %d confine %d mgpcg %d steps %d vel %.1f cfg %s" % (
             case, nx, ny, nz, world, scheme, k, confine, mgpcg, steps, vel, os.environ["FS_JACOBI_CFG"])
+        if mgpcg:
+            desc += " levels %d tb_min %s ghost %s" % (mg_level, os.environ["FS_MG_TB_MIN"], os.environ["FS_MG_SLAB_GHOST"])
         bad = []
         s = o = None
         t_case = time.time()
