@@ -126,6 +126,8 @@ def load_pmc(kernel, workload):
 def rocprof_kernel_name(stage, cfg, scheme, fused_div, slab):
     mac, halo = ("true" if scheme else "false"), ("true" if slab else "false")
     if stage == "jacobi":
+        if cfg.get("sweeps_per_pass", 4) > 4:
+            return "k_jacobi_deep<%d, 48, %d>" % (cfg["sweeps_per_pass"], cfg.get("deep_nontemporal_stores", 0))
         nty = cfg.get("tile_rows", 64)
         return "k_jacobi_tb<0, 4, %d, 1, %d, %d>" % (nty, cfg.get("aligned_rows", 0), cfg.get("nontemporal_stores", 0))
     if stage == "advect_velocity":
@@ -472,7 +474,9 @@ def main():
             "autotune": {"jacobi_tile_variant": cfg["variant"], "jacobi_tile_rows": cfg["tile_rows"],
                          "jacobi_aligned_rows": cfg["aligned_rows"], "jacobi_planes_per_chunk": cfg["planes_per_chunk"],
                          "jacobi_nontemporal_stores": cfg["nontemporal_stores"],
-                         "jacobi_sweeps_per_pass": cfg.get("sweeps_per_pass")},
+                         "jacobi_sweeps_per_pass": cfg.get("sweeps_per_pass"),
+                         "jacobi_deep_planes_per_chunk": cfg.get("deep_planes_per_chunk"),
+                         "jacobi_deep_nontemporal_stores": cfg.get("deep_nontemporal_stores")},
             "rccl_ranks": solver.comm_ranks if world > 1 else 0,
             "roofline": {
                 "stage": dom,

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "fs_velocity_host", "fs_field_host", "fs_field_host_begin", "fs_field_host_end", "fs_field_size", "fs_field_upload", "fs_field_fill", "fs_field_device",
     "fs_residual", "fs_residual_noalloc", "fs_last_sweeps", "fs_cg_residual", "fs_last_error", "fs_version",
     "fs_profile_enable", "fs_profile_read", "fs_profile_reset", "fs_halo_wait",
-    "fs_comm_unique_id", "fs_create_slab", "fs_slab_info", "fs_comm_ranks", "fs_jacobi_config",
+    "fs_comm_unique_id", "fs_create_slab", "fs_slab_info", "fs_comm_ranks", "fs_jacobi_config", "fs_jacobi_deep_config",
 )
 
 STAGES = ("source", "force", "advect_velocity", "advect_scalars", "divergence", "jacobi", "gradient",
@@ -121,6 +121,7 @@ def load_library():
     L.fs_residual_noalloc.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.fs_comm_ranks.argtypes = [vp]
     L.fs_jacobi_config.argtypes = [vp] + [C.POINTER(C.c_int)] * 5
+    L.fs_jacobi_deep_config.argtypes = [vp] + [C.POINTER(C.c_int)] * 3
     L.fs_cg_residual.argtypes = [vp, C.POINTER(C.c_float)]
     L.fs_profile_enable.argtypes = [vp, C.c_int]
     L.fs_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
@@ -294,8 +295,12 @@ class Solver:
         Jacobi passes."""
         v = [C.c_int() for _ in range(5)]
         self._check(self._L.fs_jacobi_config(self._handle(), *[C.byref(x) for x in v]))
-        return dict(zip(("variant", "tile_rows", "aligned_rows", "planes_per_chunk", "nontemporal_stores"),
-                        (x.value for x in v)))
+        d = dict(zip(("variant", "tile_rows", "aligned_rows", "planes_per_chunk", "nontemporal_stores"),
+                     (x.value for x in v)))
+        w = [C.c_int() for _ in range(3)]
+        self._check(self._L.fs_jacobi_deep_config(self._handle(), *[C.byref(x) for x in w]))
+        d.update(zip(("sweeps_per_pass", "deep_planes_per_chunk", "deep_nontemporal_stores"), (x.value for x in w)))
+        return d
 
     @property
     def step_graphs(self):

@@ -332,6 +332,243 @@ k_jacobi_tb(TbArgs A)
     }
 }
 
+
+// ---- deeper blocking: six sweeps per pass ---------------------------------------------------------
+//
+// k_jacobi_tb keeps three planes of every intermediate level in registers (z-1, z, z+1 of the cell's
+// own column), which is what limits it to four sweeps per pass.  k_jacobi_deep keeps two values per
+// level instead: the level's latest plane c, and a = (x- + x+) + z-, the head of the next level's sum
+// for that plane, formed when the plane is produced.  When the following plane arrives (it is the z+
+// neighbour), the next level finishes the sum in the reference's order,
+//     ((((pl + pr) + pbh) + pf) + pbo) + pt - div            (Solver.cu:441)
+// so every value is still the reference expression of the previous level, bit for bit.  At T = 6
+// that is 2 T + (T + 2) + 2 = 22 float4 of state per thread; the steady-state step body needs 152
+// registers with its temporaries, which fits 12 waves per CU (168 registers), not 16 (128): tiles
+// are 64 cells x 48 rows, one row of 16 lanes per tile row.  The y-neighbours go through LDS as in
+// k_jacobi_tb (one plane per level, double buffered, one barrier per step: 2 x 6 x 12 KB).  In x the
+// geometry is that of the 64-byte aligned variant of k_jacobi_tb (two halo quads per side: enough
+// for up to eight sweeps, output rows of 48 cells starting on a 64-byte boundary), in y a tile
+// loses T rows per side.  Nothing may spill: a reload from scratch is a vector-memory operation and
+// waiting for it (they complete in order) would also wait for the loads of the planes ahead.
+// Measured at 512^3: 488 us per pass of six sweeps against 376 us per pass of four (81 vs 94 us per
+// sweep); at 256^3, where the fields stay in the Infinity Cache and the passes are bound by on-chip
+// work, the four-sweep pass wins, so the choice is one more outcome of the timing at creation.
+template <int T>
+struct DeepRegs {
+    f4 q[2];        // p of plane k while its load is in flight (planes n+1, n+2 at step n)
+    f4 c[T];        // level l (0..T-1): its latest plane, n - l at the end of step n
+    f4 a[T];        // (x- + x+) + z- of that plane
+    f4 dv[T + 2];   // div of plane k at k % (T+2): planes n-T..n-1 in use, n landed, n+1 in flight
+};
+
+struct DeepLane {
+    int ld_off, st_off;          // byte offsets in a plane (see TbLane)
+    int row, row_dn, row_up;     // own LDS row and those of the clamped y-neighbours
+    bool at_left, at_right;
+    int tx;
+};
+
+// Level l+1 of march step n: finishes plane k = n-l-1 of level l+1 from the head a[l], the plane nw
+// of level l that has just been produced (plane k+1, the z+ neighbour), the y-neighbours pbo, pt of
+// plane k (read from LDS by the caller) and div; then replaces the state of level l by that of plane
+// nw and hands nw to the other waves through LDS.  Returns the finished plane.
+// WALLS: the step is one of the few in which some level touches a z wall (clamped neighbours,
+// Solver.cu:437-438): beyond the far wall the z+ neighbour is the plane itself, and plane 0 is its
+// own z- neighbour.  The steady-state body is compiled without those selects.
+template <int T, int NTY, int PH, bool WALLS, int l>
+__device__ __forceinline__ f4 deep_level(int n, const f4 nw, const f4 pbo, const f4 pt, DeepRegs<T>& R,
+                                         const DeepLane& L, const TbArgs& A, f4* lwr)
+{
+    constexpr int H = NTY, RING = T + 2;
+    const int k = n - l - 1;
+    const f4 d = R.dv[wrap(PH - l - 1, RING)];
+    const f4 h = R.a[l];
+    f4 pf = nw, zm = R.c[l];
+    if constexpr (WALLS) {
+        const bool far = k == A.nz - 1, near = k + 1 == 0;
+        pf = f4{far ? zm.x : nw.x, far ? zm.y : nw.y, far ? zm.z : nw.z, far ? zm.w : nw.w};
+        zm = f4{near ? nw.x : zm.x, near ? nw.y : zm.y, near ? nw.z : zm.z, near ? nw.w : zm.w};
+    }
+    f4 r;
+    r.x = fsk::div6((((h.x + pf.x) + pbo.x) + pt.x) - d.x);
+    r.y = fsk::div6((((h.y + pf.y) + pbo.y) + pt.y) - d.y);
+    r.z = fsk::div6((((h.z + pf.z) + pbo.z) + pt.z) - d.z);
+    r.w = fsk::div6((((h.w + pf.w) + pbo.w) + pt.w) - d.w);
+    // plane nw becomes the level's latest: the head of its sum, (pl + pr) + pbh
+    float lft = row_prev(nw.w), rgt = row_next(nw.x);
+    if (L.at_left) lft = nw.x;
+    if (L.at_right) rgt = nw.w;
+    float ax = (lft + nw.y) + zm.x, ay = (nw.x + nw.z) + zm.y, az = (nw.y + nw.w) + zm.z, aw = (nw.z + rgt) + zm.w;
+    // The head is not used before the next step.  Pin its evaluation here: left to itself the
+    // compiler sinks the heads of all levels to the end of the step, which keeps the old and the new
+    // plane of every level alive at once and spills.
+    asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(aw));
+    R.a[l] = f4{ax, ay, az, aw};
+    R.c[l] = nw;
+    lwr[l * H * kW4] = nw;       // into the buffer the next step reads
+    return r;
+}
+
+// levels l .. T-1 of a step; the LDS reads of a level are issued before the level below it computes
+template <int T, int NTY, int PH, bool WALLS, int l>
+__device__ __forceinline__ f4 deep_levels(int n, const f4 nw, const f4 pbo, const f4 pt, DeepRegs<T>& R,
+                                          const DeepLane& L, const TbArgs& A, const f4* lrd, f4* lwr)
+{
+    constexpr int H = NTY;
+    if constexpr (l + 1 < T) {
+        const f4 pbo2 = lrd[((l + 1) * H + L.row_dn) * kW4];
+        const f4 pt2 = lrd[((l + 1) * H + L.row_up) * kW4];
+        const f4 r = deep_level<T, NTY, PH, WALLS, l>(n, nw, pbo, pt, R, L, A, lwr);
+        return deep_levels<T, NTY, PH, WALLS, l + 1>(n, r, pbo2, pt2, R, L, A, lrd, lwr);
+    } else {
+        return deep_level<T, NTY, PH, WALLS, l>(n, nw, pbo, pt, R, L, A, lwr);
+    }
+}
+
+template <int T, int NTY, int PH, int NT, bool WALLS>
+__device__ __forceinline__ void deep_step(int n, DeepRegs<T>& R, const DeepLane& L, const TbArgs& A, const TbRange& Z,
+                                          f4* lds)
+{
+    constexpr int H = NTY, RING = T + 2;
+    static_assert(RING % 2 == 0, "the load slots and the LDS buffers alternate with the ring");
+    constexpr int cur = PH & 1, prv = cur ^ 1;              // LDS buffer written / read by this step
+    const f4* lrd = lds + prv * (T * H * kW4) + L.tx;
+    f4* lwr = lds + cur * (T * H * kW4) + L.row * kW4 + L.tx;
+    const f4 pbo = lrd[L.row_dn * kW4], pt = lrd[L.row_up * kW4];
+    const int kp = min(max(n + 2, Z.n_begin), Z.n_end - 1);
+    const int kd = min(max(n + 1, Z.n_begin), Z.n_end - 1);
+    f4 nw = R.q[PH & 1];                                    // plane n of level 0 has landed
+    R.q[PH & 1] = plane_load(plane_rsrc(A.p, kp, A), L.ld_off);
+    R.dv[wrap(PH + 1, RING)] = plane_load(plane_rsrc(A.div, kd, A), L.ld_off);
+    nw = deep_levels<T, NTY, PH, WALLS, 0>(n, nw, pbo, pt, R, L, A, lrd, lwr);
+    const int k = n - T;                                    // plane of level T that is complete now
+    if (k >= Z.out_lo && k < Z.out_hi)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, nw), plane_rsrc(A.np, k, A), L.st_off, 0, NT ? 2 : 0);
+    __syncthreads();
+}
+
+// The march chains the T + 2 = 8 step bodies (one per residue of the ring indices).
+// deep_run: steps n .. end-1 entering the chain at its head (n and the chain in phase); returns the
+// body the step after the last one takes.  deep_finish: steps n .. end-1 entering the chain at body ph.
+// Both leave n = end.  The chain entered at its head is what the steady state runs: its bodies are
+// reached in one way only, so the register assignment rotates through them without copies; the
+// chain with entry points at every body is for the few closing steps.
+template <int T, int NTY, int NT, bool WALLS>
+__device__ __forceinline__ int deep_run(int& n, int end, DeepRegs<T>& R, const DeepLane& L, const TbArgs& A,
+                                        const TbRange& Z, f4* lds)
+{
+    static_assert(T + 2 == 8, "eight step bodies");
+    if (n >= end) return 0;
+#define FS_DEEP_STEP(PH)                                           \
+    deep_step<T, NTY, PH, NT, WALLS>(n, R, L, A, Z, lds);  \
+    if (++n >= end) return (PH + 1) & 7;
+    for (;;) {
+        FS_DEEP_STEP(0)
+        FS_DEEP_STEP(1)
+        FS_DEEP_STEP(2)
+        FS_DEEP_STEP(3)
+        FS_DEEP_STEP(4)
+        FS_DEEP_STEP(5)
+        FS_DEEP_STEP(6)
+        FS_DEEP_STEP(7)
+    }
+#undef FS_DEEP_STEP
+}
+
+template <int T, int NTY, int NT, bool WALLS>
+__device__ __forceinline__ void deep_finish(int& n, int ph, int end, DeepRegs<T>& R, const DeepLane& L, const TbArgs& A,
+                                            const TbRange& Z, f4* lds)
+{
+    if (n >= end) return;
+#define FS_DEEP_STEP(PH)                                               \
+    case PH:                                                           \
+        deep_step<T, NTY, PH, NT, WALLS>(n, R, L, A, Z, lds);  \
+        if (++n >= end) return;                                        \
+        [[fallthrough]];
+    for (;;) {
+        switch (ph) {
+            FS_DEEP_STEP(0)
+            FS_DEEP_STEP(1)
+            FS_DEEP_STEP(2)
+            FS_DEEP_STEP(3)
+            FS_DEEP_STEP(4)
+            FS_DEEP_STEP(5)
+            FS_DEEP_STEP(6)
+            FS_DEEP_STEP(7)
+        default: break;
+        }
+        ph = 0;
+    }
+#undef FS_DEEP_STEP
+}
+
+template <int T, int NTY, int NT>
+__global__ void __launch_bounds__(kW4 * NTY)
+k_jacobi_deep(TbArgs A)
+{
+    constexpr int H = NTY, BY = H - 2 * T, RING = T + 2;
+    static_assert(T > kHaloX && T <= 2 * kHaloX, "two halo quads per side in x");
+    static_assert(BY > 0, "tile too small");
+    static_assert(RING == 8, "the march below chains eight step bodies");
+    __shared__ f4 lds[2 * T * H * kW4];
+
+    DeepLane L;
+    L.tx = threadIdx.x;
+    const int row = threadIdx.y;
+    const int lid = A.order ? xcd_contiguous((int)blockIdx.x, A.nblocks) : (int)blockIdx.x;
+    const int bz = lid / (A.tiles_x * A.tiles_y);
+    const int rem = lid - bz * (A.tiles_x * A.tiles_y);
+    const int by = rem / A.tiles_x;
+    const int bx = rem - by * A.tiles_x;
+    // tile (bx, by) covers cells [bx*48 - 8, bx*48 + 56) x [by*BY, by*BY + H), H = NTY rows; the
+    // outer two quads and T rows are halo except where the tile edge is a wall
+    const int x = bx * tile_bx(1) + 4 * L.tx - 8;
+    const bool x_in = x >= 0 && x < A.nx;
+    L.at_left = x == 0;
+    L.at_right = x + 4 == A.nx;
+    const bool x_out = L.tx >= 2 && L.tx < kW4 - 2;
+    const int xc = max(0, min(x, A.nx - 4));
+    const int y0 = by * BY, y = y0 + row;
+    L.row = row;
+    L.row_dn = (y == 0 || row == 0) ? row : row - 1;
+    L.row_up = (y == A.ny - 1 || row == H - 1) ? row : row + 1;
+    const bool store = x_in && y < A.ny && x_out && (row >= T || y0 == 0) && (row < H - T || y0 + H >= A.ny);
+    L.st_off = store ? (x + y * A.pitch) * 4 : (int)0xfffffff0u;
+    L.ld_off = (xc + min(y, A.ny - 1) * A.pitch) * 4;
+
+    TbRange Z;
+    Z.y0 = y0;
+    const bool second = bz >= A.chunks1;
+    Z.out_lo = second ? A.zout2_lo + (bz - A.chunks1) * A.lz : A.zout_lo + bz * A.lz;
+    Z.out_hi = min(Z.out_lo + A.lz, second ? A.zout2_hi : A.zout_hi);
+    Z.n_begin = max(Z.out_lo - T, A.zin_lo);
+    Z.n_end = min(Z.out_hi + T, A.zin_hi);
+
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    DeepRegs<T> R;
+    R.q[0] = R.q[1] = zero;
+#pragma unroll
+    for (int i = 0; i < T; ++i) R.c[i] = R.a[i] = zero;
+#pragma unroll
+    for (int i = 0; i < RING; ++i) R.dv[i] = zero;
+    // the LDS planes are read (by the levels, which run on every step) before the first step has
+    // written them: start from zeros, so that no step computes on uninitialised memory
+#pragma unroll
+    for (int i = 0; i < 2 * T; ++i) lds[(i * H + row) * kW4 + L.tx] = zero;
+    __syncthreads();
+
+    // The march runs from two steps before the first plane (those steps only issue the first loads)
+    // until the last level has drained.  A level touches a z wall only in the first T steps of a
+    // march that starts at the near wall and in the last T steps of one that reaches the far wall:
+    // those steps take the step bodies with the wall selects, all others the plain ones.
+    const int last = Z.n_end + T;
+    int n = Z.n_begin - 2;
+    // (a march from the near wall: n = -2 .. T-1, exactly once through the chain, T + 2 <= last)
+    if (Z.n_begin == 0) deep_run<T, NTY, NT, true>(n, T, R, L, A, Z, lds);
+    const int ph = deep_run<T, NTY, NT, false>(n, Z.n_end == A.nz ? min(A.nz, last) : last, R, L, A, Z, lds);
+    deep_finish<T, NTY, NT, true>(n, ph, last, R, L, A, Z, lds);
+}
+
 // plain one-sweep kernel (any nx): one cell per thread
 __global__ void k_jacobi_1(const float* __restrict__ p, float* __restrict__ np,
                            const float* __restrict__ div, int nx, int ny, int nz, int pitch, int plane,
@@ -450,6 +687,70 @@ void launch_tb(hipStream_t st, const FsGrid& g, const float* p, float* np, const
     case 3: launch_tb_cfg<KIND, T, 32, 1, 1>(st, g, A); break;
     default: launch_tb_cfg<KIND, T, 64, 1>(st, g, A); break;
     }
+}
+
+constexpr int kTDeep = 6;      // sweeps fused per pass of k_jacobi_deep
+constexpr int kDeepRows = 48;  // its tile rows = rows of threads of a workgroup (12 waves)
+
+bool can_deep(const FsGrid& g) { return can_block(g) && g.ny >= 2 * kTDeep + 2 && g.nzl >= 2 * kTDeep; }
+
+// one pass of kTDeep sweeps over a single domain (both z faces global walls)
+void launch_deep(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div)
+{
+    constexpr int T = kTDeep, NTY = kDeepRows, BY = NTY - 2 * T;
+    TbArgs A;
+    A.kpar = 0;
+    ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
+    A.p = p - zoff;
+    A.np = np - zoff;
+    A.div = div - zoff;
+    A.nx = g.nx; A.ny = g.ny; A.nz = g.nz;
+    A.pitch = g.pitch; A.plane = g.plane;
+    A.zin_lo = g.z0; A.zin_hi = g.z0 + g.nzl;
+    A.zout_lo = g.z0; A.zout_hi = g.z0 + g.nzl;
+    A.zout2_lo = A.zout2_hi = 0;
+    const int nout = g.nzl;
+    const int tiles_x = cdiv(g.nx, tile_bx(1)), tiles_y = max(1, cdiv(g.ny - 2 * T, BY));
+    // z chunks: as for k_jacobi_tb, one workgroup per CU
+    int chunks = 1;
+    double best = -1.0;
+    for (int c = 1; c <= max(1, nout / 12); ++c) {
+        const double r = (double)tiles_x * tiles_y * c / 256.0;
+        const double steps = cdiv(nout, c) + 2 * T + 2;
+        const double cost = r <= 1.0 ? steps / r : (r < 2.5 ? cdiv(tiles_x * tiles_y * c, 256) * steps : 0.95 * r * steps);
+        if (best < 0 || cost < best) {
+            best = cost;
+            chunks = c;
+        }
+    }
+    A.lz = cdiv(nout, chunks);
+    if (g.jacobi_deep_lz > 0) A.lz = min(nout, g.jacobi_deep_lz);
+    if (g.env.jacobi_deep_lz > 0) A.lz = min(nout, g.env.jacobi_deep_lz);
+    A.chunks1 = cdiv(nout, A.lz);
+    A.tiles_x = tiles_x;
+    A.tiles_y = tiles_y;
+    A.nblocks = tiles_x * tiles_y * A.chunks1;
+    A.order = g.env.jacobi_order;
+    dim3 grid(A.nblocks), block(kW4, NTY);
+    if (g.env.jacobi_deep_nt >= 0 ? g.env.jacobi_deep_nt != 0 : g.jacobi_deep_nt != 0)
+        hipLaunchKernelGGL((k_jacobi_deep<T, NTY, 1>), grid, block, 0, st, A);
+    else hipLaunchKernelGGL((k_jacobi_deep<T, NTY, 0>), grid, block, 0, st, A);
+}
+
+// How `sweeps` sweeps are cut into passes of kTDeep and kT sweeps and single sweeps when the deep
+// passes are on: as many deep passes as leave a remainder that passes of kT sweeps take whole, if
+// there is such a split; else deep passes first.
+void deep_split(int sweeps, int* deep, int* four, int* single)
+{
+    *deep = sweeps / kTDeep;
+    for (int d = sweeps / kTDeep; d >= 0 && d >= sweeps / kTDeep - 1; --d)
+        if ((sweeps - d * kTDeep) % kT == 0) {
+            *deep = d;
+            break;
+        }
+    const int left = sweeps - *deep * kTDeep;
+    *four = left / kT;
+    *single = left % kT;
 }
 
 }  // namespace
@@ -574,11 +875,68 @@ void tune_tb(hipStream_t st, FsGrid& g, int nout, const char* what, Pass&& pass,
     (void)hipEventDestroy(b);
 }
 
+// Times the six-sweep pass against the four-sweep pass g is set up with (per sweep), over chunk
+// counts and both store policies.
+static void tune_deep(hipStream_t st, FsGrid& g, float* x, float* y, const float* div, int* deep, int* deep_lz, int* deep_nt)
+{
+    *deep = *deep_lz = *deep_nt = 0;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return;
+    if (hipEventCreate(&b) != hipSuccess) {
+        (void)hipEventDestroy(a);
+        return;
+    }
+    const bool verbose = g.env.jacobi_tune == 2;
+    const int nout = g.nzl, timed = (long)g.nx * g.ny * nout >= 384L * 384L * 384L ? 3 : 12;
+    auto time_of = [&](auto&& pass) {
+        pass();
+        (void)hipEventRecord(a, st);
+        for (int i = 0; i < timed; ++i) pass();
+        (void)hipEventRecord(b, st);
+        float ms = -1.f;
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.f;
+        return ms / timed;
+    };
+    const float four = time_of([&] {
+        launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, g.z0, g.z0 + g.nzl);
+        float* t = x; x = y; y = t;
+    });
+    float best = -1.f;
+    const int chunk_counts[] = {0, 1, 2, 3, 4, 5, 6, 8};
+    for (int nt = 0; nt < 2; ++nt)
+        for (int cc : chunk_counts) {
+            const int lz = cc ? cdiv(nout, cc) : 0;
+            if (cc && lz < 2 * kTDeep) continue;
+            g.jacobi_deep_lz = lz;
+            g.jacobi_deep_nt = nt;
+            const float ms = time_of([&] {
+                launch_deep(st, g, x, y, div);
+                float* t = x; x = y; y = t;
+            });
+            if (verbose) fprintf(stderr, "jacobi_autotune %dx%dx%d: six-sweep pass, %d planes per chunk, nt %d: %.1f us "
+                                 "(four-sweep pass: %.1f)\n", g.nx, g.ny, nout, lz, nt, 1e3f * ms, 1e3f * four);
+            if (ms > 0.f && (best < 0.f || ms < best)) {
+                best = ms;
+                *deep_lz = lz;
+                *deep_nt = nt;
+            }
+        }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    g.jacobi_deep_lz = g.jacobi_deep_nt = 0;
+    // a sweep of the six-sweep pass has to be cheaper by more than the noise of these readings
+    if (g.env.jacobi_deep == 1 || (best > 0.f && four > 0.f && best / kTDeep < 0.97f * four / kT)) *deep = 1;
+    else *deep_lz = *deep_nt = 0;
+}
+
 void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float* div)
 {
     g.jacobi_tile = 0;
     g.jacobi_lz = 0;
     g.jacobi_nt = 0;
+    g.jacobi_deep = g.jacobi_deep_lz = g.jacobi_deep_nt = 0;
+    // FS_JACOBI_DEEP=1 forces the six-sweep passes wherever they can run (tests), also without timing
+    if (g.env.jacobi_deep == 1 && can_deep(g) && g.wall_lo && g.wall_hi) g.jacobi_deep = 1;
     // what a slab's interior launch produces: planes whose T-sweep cone stays inside the owned
     // planes (a pass may only store planes it holds T input planes around, except at a wall)
     const int out_lo = g.z0 + (g.wall_lo ? 0 : kT), out_hi = g.z0 + g.nzl - (g.wall_hi ? 0 : kT);
@@ -586,7 +944,7 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
     // one timing per grid shape and process: solvers created later on the same shape take the
     // remembered choice, so they cost no timing passes and run the same variant
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int>, std::tuple<int, int, int>> tuned;
+    static std::map<std::tuple<int, int, int, int, int>, std::tuple<int, int, int, int, int, int>> tuned;
     std::lock_guard<std::mutex> lock(mu);
     if (g.env.jacobi_tune == 0) return;   // (and a solver created without the switch still gets its timing)
     const auto key = std::make_tuple(g.nx, g.ny, g.nzl, g.wall_lo, g.wall_hi);
@@ -597,11 +955,20 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
             launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
             float* t = x; x = y; y = t;
         }, true);
-        it = tuned.emplace(key, std::make_tuple(g.jacobi_tile, g.jacobi_lz, g.jacobi_nt)).first;
+        // the six-sweep passes (single domain, planes large enough for 64-row tiles): their own
+        // chunking and store policy, then kept if a sweep is cheaper than in the best four-sweep pass
+        int deep = 0, deep_lz = 0, deep_nt = 0;
+        if (g.env.jacobi_deep != 0 && can_deep(g) && g.wall_lo && g.wall_hi && (long)g.nx * g.ny >= 224L * 224L)
+            tune_deep(st, g, x, y, div, &deep, &deep_lz, &deep_nt);
+        it = tuned.emplace(key, std::make_tuple(g.jacobi_tile, g.jacobi_lz, g.jacobi_nt, deep, deep_lz, deep_nt)).first;
     }
     g.jacobi_tile = std::get<0>(it->second);
     g.jacobi_lz = std::get<1>(it->second);
     g.jacobi_nt = std::get<2>(it->second);
+    g.jacobi_deep = std::get<3>(it->second);
+    g.jacobi_deep_lz = std::get<4>(it->second);
+    g.jacobi_deep_nt = std::get<5>(it->second);
+    if (g.env.jacobi_deep == 1 && can_deep(g) && g.wall_lo && g.wall_hi) g.jacobi_deep = 1;   // forced (tests)
 }
 
 bool jacobi_can_block(const FsGrid& g) { return can_block(g); }
@@ -615,6 +982,14 @@ void jacobi_config(const FsGrid& g, int* variant, int* rows, int* aligned, int* 
     *rows = v >= 0 ? kConfigs[v].nty * kConfigs[v].cpt : 0;
     *aligned = v >= 2 ? 1 : 0;
     *planes_per_chunk = g.jacobi_lz;
+}
+
+void jacobi_deep_config(const FsGrid& g, int* sweeps_per_pass, int* planes_per_chunk, int* nontemporal)
+{
+    const bool on = g.jacobi_deep && can_deep(g) && g.wall_lo && g.wall_hi;
+    *sweeps_per_pass = on ? kTDeep : (can_block(g) ? kT : 1);
+    *planes_per_chunk = on ? g.jacobi_deep_lz : 0;
+    *nontemporal = on ? g.jacobi_deep_nt : 0;
 }
 
 bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
@@ -679,7 +1054,20 @@ bool rbgs_pass(hipStream_t st, const FsEnv& env, int nx, int ny, int nz, const f
 int jacobi_launches(const FsGrid& g, int sweeps, int naive)
 {
     if (naive || !can_block(g)) return sweeps;
+    if (g.jacobi_deep && can_deep(g) && g.wall_lo && g.wall_hi) {
+        int deep, four, single;
+        deep_split(sweeps, &deep, &four, &single);
+        return deep + four + single;
+    }
     return sweeps / kT + sweeps % kT;
+}
+
+int jacobi_deep_passes(const FsGrid& g, int sweeps, int naive)
+{
+    if (naive || !(g.jacobi_deep && can_deep(g) && g.wall_lo && g.wall_hi)) return 0;
+    int deep, four, single;
+    deep_split(sweeps, &deep, &four, &single);
+    return deep;
 }
 
 // Single-slab driver: both z faces of the slab must be global walls.
@@ -688,7 +1076,16 @@ void jacobi_multi(hipStream_t st, const FsGrid& g, float* p, float* np, const fl
 {
     float *a = p, *b = np;
     int left = sweeps;
-    *prev_held = sweeps > 0 && (naive || !can_block(g) || sweeps % kT != 0);
+    if (!naive && g.jacobi_deep && can_deep(g) && g.wall_lo && g.wall_hi) {
+        int deep, four, single;
+        deep_split(sweeps, &deep, &four, &single);
+        for (int q = 0; q < deep; ++q) {
+            launch_deep(st, g, a, b, div);
+            float* t = a; a = b; b = t;
+        }
+        left -= deep * kTDeep;
+    }
+    *prev_held = sweeps > 0 && (naive || !can_block(g) || left % kT != 0);
     if (!naive && can_block(g)) {
         for (; left >= kT; left -= kT) {
             launch_tb<kT>(st, g, a, b, div, g.z0, g.z0 + g.nzl, g.z0, g.z0 + g.nzl);

@@ -21,6 +21,8 @@ struct FsEnv {
     int jacobi_lz = 0;            // FS_JACOBI_LZ     planes per z chunk, 0 = timed / cost model
     int jacobi_tune = 1;          // FS_JACOBI_TUNE   0 = no timing at creation, 2 = print the readings
     int jacobi_deep = -1;         // FS_JACOBI_DEEP   1 / 0 force / forbid the six-sweep passes, -1 = timed
+    int jacobi_deep_lz = 0;       // FS_JACOBI_DEEP_LZ  planes per z chunk of a six-sweep pass, 0 = timed / cost model
+    int jacobi_deep_nt = -1;      // FS_JACOBI_DEEP_NT  its store policy, -1 = timed
     int advect_global = 0;        // FS_ADVECT_GLOBAL bit 0 / 1: velocity / scalar advection without LDS bricks
     int advect_brick = 1;         // FS_ADVECT_BRICK  1 = narrow LDS brick, 0 = wide
     long mg_tb_min = 128L * 128L; // FS_MG_TB_MIN     smallest plane (cells) smoothed by the blocked kernel
@@ -49,6 +51,9 @@ struct FsGrid {
     int jacobi_tile;  // 1 + tile variant of the blocked Jacobi kernel chosen for this grid, 0 = by rule
     int jacobi_lz;    // planes per z chunk of a blocked pass chosen for this grid, 0 = by the cost model
     int jacobi_nt;    // 1 = the blocked Jacobi passes of this grid store with the non-temporal policy
+    int jacobi_deep;      // 1 = a single domain runs its sweeps in passes of six where it can
+    int jacobi_deep_lz;   // planes per z chunk of a six-sweep pass, 0 = by the cost model
+    int jacobi_deep_nt;   // 1 = the six-sweep passes store with the non-temporal policy
     FsEnv env;        // the environment switches as they stood when the solver was created
 };
 
@@ -139,6 +144,11 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
 // tile rows, whether its output rows are 64-byte aligned, planes per z chunk (0 = cost model)
 void jacobi_config(const FsGrid& g, int* variant, int* rows, int* aligned, int* planes_per_chunk);
 int jacobi_nontemporal(const FsGrid& g);
+// the deepest pass of this grid: sweeps it fuses (6 with the six-sweep passes on, else 4, or 1 if the
+// grid cannot block), its planes per z chunk and store policy when that is the six-sweep pass
+void jacobi_deep_config(const FsGrid& g, int* sweeps_per_pass, int* planes_per_chunk, int* nontemporal);
+// six-sweep passes among the launches jacobi_multi makes for `sweeps` sweeps
+int jacobi_deep_passes(const FsGrid& g, int sweeps, int naive);
 int jacobi_block();   // sweeps fused per pass
 // number of kernel launches jacobi_multi makes for `sweeps` sweeps
 int jacobi_launches(const FsGrid& g, int sweeps, int naive);

@@ -390,6 +390,8 @@ FsEnv read_env()
     geti("FS_JACOBI_LZ", v.jacobi_lz);
     geti("FS_JACOBI_TUNE", v.jacobi_tune);
     geti("FS_JACOBI_DEEP", v.jacobi_deep);
+    geti("FS_JACOBI_DEEP_LZ", v.jacobi_deep_lz);
+    geti("FS_JACOBI_DEEP_NT", v.jacobi_deep_nt);
     geti("FS_ADVECT_GLOBAL", v.advect_global);
     geti("FS_ADVECT_BRICK", v.advect_brick);
     if (const char* e = getenv("FS_MG_TB_MIN")) v.mg_tb_min = atol(e);

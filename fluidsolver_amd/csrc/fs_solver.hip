@@ -453,6 +453,18 @@ int fs_jacobi_config(const fs_solver* s, int* variant, int* tile_rows, int* alig
     return FS_OK;
 }
 
+int fs_jacobi_deep_config(const fs_solver* s, int* sweeps_per_pass, int* planes_per_chunk, int* nontemporal_stores)
+{
+    if (!s) return fail(FS_ERR_INVALID, "null solver");
+    int t, lz, nt;
+    fsk::jacobi_deep_config(s->g, &t, &lz, &nt);
+    if (s->world > 1 && t > fsk::jacobi_block()) t = fsk::jacobi_block();
+    if (sweeps_per_pass) *sweeps_per_pass = t;
+    if (planes_per_chunk) *planes_per_chunk = lz;
+    if (nontemporal_stores) *nontemporal_stores = nt;
+    return FS_OK;
+}
+
 int fs_sync(fs_solver* s)
 {
     if (!s) return fail(FS_ERR_INVALID, "null solver");

@@ -169,6 +169,12 @@ FS_API int fs_comm_ranks(const fs_solver* s);
    whether the passes store with the non-temporal cache policy.  Any pointer may be NULL. */
 FS_API int fs_jacobi_config(const fs_solver* s, int* variant, int* tile_rows, int* aligned_rows,
                             int* planes_per_chunk, int* nontemporal_stores);
+/* The deepest pass this solver's Jacobi sweeps run in (no counterpart in the reference): sweeps
+   fused per pass (6 where the timing at creation found the six-sweep passes faster on a single
+   domain, else 4, 1 on grids the blocked kernels cannot take) and, for the six-sweep pass, its
+   planes per z chunk (0 = cost model) and store policy.  Any pointer may be NULL. */
+FS_API int fs_jacobi_deep_config(const fs_solver* s, int* sweeps_per_pass, int* planes_per_chunk,
+                                 int* nontemporal_stores);
 
 /* -- stepping: replaces Solver::Update -> UpdateCuda (Solver.cu:1009-1114, 1132-1137)
       with VORT_CONFINE off and Project() on its Jacobi branch (Solver.cu:1178-1189) -- */

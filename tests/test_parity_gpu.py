@@ -118,6 +118,30 @@ def test_jacobi_tile_variants(fs, oracle, dims, cfg, monkeypatch):
         g.close(); o.close()
 
 
+@pytest.mark.parametrize("dims", [(132, 70, 23), (64, 61, 13), (60, 124, 40), (8, 14, 12), (196, 130, 12), (48, 36, 30)])
+def test_jacobi_six_sweep_passes(fs, oracle, dims, monkeypatch):
+    """FS_JACOBI_DEEP=1: a single domain runs its sweeps in passes of six (two values per level in
+    registers instead of three planes) wherever it can; 6, 12, 14 (6 + 4 + 4), 8 (4 + 4), 9 (6 + three
+    single sweeps) and 20 (6 + 6 + 4 + 4) sweeps on grids with several tiles per direction, tile edges
+    on walls and in mid-tile, fewer planes than a march needs to fill, and both store policies."""
+    monkeypatch.setenv("FS_JACOBI_DEEP", "1")
+    nx, ny, nz = dims
+    for sweeps in (6, 12, 14, 8, 9, 20):
+        monkeypatch.setenv("FS_JACOBI_DEEP_LZ", "0" if sweeps != 12 else "7")     # chunks shorter than their ramp
+        monkeypatch.setenv("FS_JACOBI_DEEP_NT", "1" if sweeps == 14 else "0")
+        g, o = make_pair(fs, oracle, nx, ny, nz, jacobi_iters=sweeps)
+        st = random_fields(nx, ny, nz, seed=131 + sweeps)
+        load_state(g, o, st)
+        g.stage("jacobi", sweeps)
+        p, div = st[5], st[6]
+        for _ in range(sweeps):
+            p, _r = oracle.jacobi(p, div, want_r=False)
+        got = g.field(fs.FS_P)
+        assert np.array_equal(got, p), "dims %s, %d sweeps: %d mismatches" % (dims, sweeps, int((got != p).sum()))
+        assert g.jacobi_config()["sweeps_per_pass"] == 6
+        g.close(); o.close()
+
+
 @pytest.mark.parametrize("brick", [0, 1])
 @pytest.mark.parametrize("scheme", [0, 1])
 @pytest.mark.parametrize("dims", [(24, 20, 18), (33, 9, 14)])

@@ -19,8 +19,10 @@ eval $(python3 - "$OUT/stats.log" <<'PY'
 import json, sys
 line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
 a = json.loads(line)["autotune"]
-print("export FS_JACOBI_TUNE=0 FS_JACOBI_CFG=%d FS_JACOBI_NT=%d FS_JACOBI_DEEP=%d" % (
-    max(a["jacobi_tile_variant"], 0), a["jacobi_nontemporal_stores"], 1 if (a.get("jacobi_sweeps_per_pass") or 4) > 4 else 0))
+deep = (a.get("jacobi_sweeps_per_pass") or 4) > 4
+print("export FS_JACOBI_TUNE=0 FS_JACOBI_CFG=%d FS_JACOBI_NT=%d FS_JACOBI_DEEP=%d FS_JACOBI_DEEP_LZ=%d FS_JACOBI_DEEP_NT=%d" % (
+    max(a["jacobi_tile_variant"], 0), a["jacobi_nontemporal_stores"], 1 if deep else 0,
+    (a.get("jacobi_deep_planes_per_chunk") or 0) if deep else 0, (a.get("jacobi_deep_nontemporal_stores") or 0) if deep else 0))
 if a["jacobi_planes_per_chunk"] > 0:
     print("export FS_JACOBI_LZ=%d" % a["jacobi_planes_per_chunk"])
 PY
