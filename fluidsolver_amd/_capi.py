@@ -16,6 +16,7 @@ FS_FLAG_NO_GRAPH = 1 << 0
 FS_FLAG_JACOBI_NAIVE = 1 << 1
 FS_FLAG_VORT_CONFINE = 1 << 2
 FS_FLAG_TEST_SELF_PEER = 1 << 3
+FS_FLAG_FMAD = 1 << 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -30,6 +30,7 @@ Solver& Solver::operator=(Solver&& other) noexcept
 		jacobi_iters = other.jacobi_iters;
 		vort_confine = other.vort_confine;
 		mgpcg = other.mgpcg;
+		fmad = other.fmad;
 		curl_strength = other.curl_strength;
 		other.handle = nullptr;
 	}
@@ -44,6 +45,7 @@ void Solver::InitializeGrid(int nx, int ny, int nz)
 	if (vort_confine) p.flags |= FS_FLAG_VORT_CONFINE;
 	p.curl_strength = curl_strength;
 	if (mgpcg) p.pressure_solver = FS_PRESSURE_MGPCG;
+	if (fmad) p.flags |= FS_FLAG_FMAD;
 	if (handle) fs_destroy(handle);
 	handle = nullptr;
 	check(fs_create(&p, &handle), "fs_create");

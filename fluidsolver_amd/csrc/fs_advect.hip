@@ -44,19 +44,28 @@ __device__ __forceinline__ Axis split_axis(float x)
     return Axis{ix, fx};
 }
 
-// Math.cuh:57-60
-__device__ __forceinline__ float lerp1(float a, float b, float s)
-{
-    return a * (1.0f - s) + b * s;
-}
+// The two meanings of the reference's a*b + c shaped expressions.  Plain: every product and sum
+// rounded on its own, the meaning of the source text and this library's default.  Fused: what a
+// compiler that contracts (nvcc's default -fmad=true, which built the reference's binary) makes of
+// them: the left product of lerp's sum of two products and the product of an RK position update fused
+// into the add (FS_FLAG_FMAD).
+struct Plain {
+    static __device__ __forceinline__ float lerp(float a, float b, float s) { return a * (1.0f - s) + b * s; }   // Math.cuh:57-60
+    static __device__ __forceinline__ float step(float p, float c, float u) { return p - c * u; }               // Solver.cu:145
+};
+struct Fused {
+    static __device__ __forceinline__ float lerp(float a, float b, float s) { return __builtin_fmaf(a, 1.0f - s, b * s); }
+    static __device__ __forceinline__ float step(float p, float c, float u) { return __builtin_fmaf(-c, u, p); }
+};
 
 // Solver.cu:109-112
+template <class AR>
 __device__ __forceinline__ float trilerp8(float a, float b, float c, float d, float e, float f,
                                           float g, float h, float fx, float fy, float fz)
 {
-    float l1 = lerp1(lerp1(a, b, fx), lerp1(c, d, fx), fy);
-    float l2 = lerp1(lerp1(e, f, fx), lerp1(g, h, fx), fy);
-    return lerp1(l1, l2, fz);
+    float l1 = AR::lerp(AR::lerp(a, b, fx), AR::lerp(c, d, fx), fy);
+    float l2 = AR::lerp(AR::lerp(e, f, fx), AR::lerp(g, h, fx), fy);
+    return AR::lerp(l1, l2, fz);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
@@ -102,6 +111,7 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t rs, unsigned voff,
 // a stored zero.  Eight dword buffer loads share one per-lane offset (row / plane steps ride in
 // the scalar offset); the x+1 taps get their own offset register, hidden from the load combiner,
 // because a dwordx2 costs the address path ~2x two dwords.
+template <class AR>
 __device__ __forceinline__ float gather_global(const Fld& F, Axis ax, Axis ay, Axis az, int dx,
                                                int dy, const ZRange& zr, int pitch, int plane)
 {
@@ -123,7 +133,7 @@ __device__ __forceinline__ float gather_global(const Fld& F, Axis ax, Axis ay, A
     float f = bload(F.rs, vo1, sq);
     float g = bload(F.rs, vo, sq + sp);
     float h = bload(F.rs, vo1, sq + sp);
-    return trilerp8(a, b, c, d, e, f, g, h, ax.f, ay.f, az.f);
+    return trilerp8<AR>(a, b, c, d, e, f, g, h, ax.f, ay.f, az.f);
 }
 
 // The velocity field as the kernels receive it (pointers pre-offset for global z).
@@ -140,7 +150,9 @@ struct Vel {
 // ---- samplers: "velocity at a point" = the three staggered gathers of one RK stage
 // (Solver.cu:142-144) --------------------------------------------------------------------
 
+template <class AR>
 struct GlobalSampler {
+    typedef AR Arith;
     static constexpr bool kHasGridStage = false;
     Fld ux, uy, uz;
     int nx, ny, pitch, plane;
@@ -163,9 +175,9 @@ struct GlobalSampler {
         if (HALO)
             bad |= (zh.i < zc.chk_lo) | (zh.i > zc.chk_hi) | (z0.i < zf.chk_lo) | (z0.i > zf.chk_hi);
         float3 u;
-        u.x = gather_global(ux, x0, yh, zh, nx + 1, ny, zc, pitch, plane);
-        u.y = gather_global(uy, xh, y0, zh, nx, ny + 1, zc, pitch, plane);
-        u.z = gather_global(uz, xh, yh, z0, nx, ny, zf, pitch, plane);
+        u.x = gather_global<AR>(ux, x0, yh, zh, nx + 1, ny, zc, pitch, plane);
+        u.y = gather_global<AR>(uy, xh, y0, zh, nx, ny + 1, zc, pitch, plane);
+        u.z = gather_global<AR>(uz, xh, yh, z0, nx, ny, zf, pitch, plane);
         return u;
     }
 };
@@ -196,10 +208,11 @@ struct SplitL {
     int i;
 };
 
-template <class D>
+template <class D, class AR>
 struct BrickSampler {
+    typedef AR Arith;
     static constexpr bool kHasGridStage = true;
-    GlobalSampler G;
+    GlobalSampler<AR> G;
     const float* lds;    // 3 * D::N floats: ux, uy, uz
     int ox, oy, oz;      // global index of LDS element 0 along each axis
     float lo_x, lo_y, lo_z, hi_x, hi_y, hi_z;   // fast-path bounds, see vel()
@@ -222,9 +235,9 @@ struct BrickSampler {
             float a = q[0], b = q[D::SX], c = q[D::SY], d = q[D::SY + D::SX];
             const float* q2 = q + D::SZ;
             float e = q2[0], f = q2[D::SX], g = q2[D::SY], h = q2[D::SY + D::SX];
-            return trilerp8(a, b, c, d, e, f, g, h, ax.f, ay.f, az.f);
+            return trilerp8<AR>(a, b, c, d, e, f, g, h, ax.f, ay.f, az.f);
         }
-        return gather_global(F, ax, ay, az, dx, dy, zr, G.pitch, G.plane);
+        return gather_global<AR>(F, ax, ay, az, dx, dy, zr, G.pitch, G.plane);
     }
     template <bool HALO>
     __device__ __forceinline__ float3 vel_general(float3 p, int& bad) const
@@ -265,7 +278,7 @@ struct BrickSampler {
         float a = q[0], b = q[D::SX], c = q[D::SY], d = q[D::SY + D::SX];
         const float* q2 = q + D::SZ;
         float e = q2[0], f = q2[D::SX], g = q2[D::SY], h = q2[D::SY + D::SX];
-        return trilerp8(a, b, c, d, e, f, g, h, sx.f, sy.f, sz.f);
+        return trilerp8<AR>(a, b, c, d, e, f, g, h, sx.f, sy.f, sz.f);
     }
     template <bool HALO>
     __device__ __forceinline__ float3 vel(float3 p, int& bad) const
@@ -292,18 +305,18 @@ struct BrickSampler {
     // ---- velocity at a sample point of the grid (first stage of the first RK4) ----
     // At a grid sample point every gather coordinate is an integer (weight 0) or an integer
     // plus one half (weight .5).  A weight-0 lerp returns its first operand for finite data
-    // (a*1 + b*0), so those taps are not read; the weight-.5 lerps run through lerp1 as usual.
+    // (a*1 + b*0, fused or not), so those taps are not read; the weight-.5 lerps run through lerp as usual.
     // MX/MY/MZ: the axis has weight .5.  q addresses the lower taps.
     template <bool MX, bool MY, bool MZ>
     static __device__ __forceinline__ float gather_grid(const float* q)
     {
-        auto X = [](const float* r) { return MX ? lerp1(r[0], r[D::SX], 0.5f) : r[0]; };
+        auto X = [](const float* r) { return MX ? AR::lerp(r[0], r[D::SX], 0.5f) : r[0]; };
         float v00 = X(q);
-        float l1 = MY ? lerp1(v00, X(q + D::SY), 0.5f) : v00;
+        float l1 = MY ? AR::lerp(v00, X(q + D::SY), 0.5f) : v00;
         if (!MZ) return l1;
         float v01 = X(q + D::SZ);
-        float l2 = MY ? lerp1(v01, X(q + D::SZ + D::SY), 0.5f) : v01;
-        return lerp1(l1, l2, 0.5f);
+        float l2 = MY ? AR::lerp(v01, X(q + D::SZ + D::SY), 0.5f) : v01;
+        return AR::lerp(l1, l2, 0.5f);
     }
     // DIR = 0 cell centre, 1/2/3 the x/y/z face of cell (i,j,k); the point is inside the brick.
     template <int DIR>
@@ -408,13 +421,14 @@ __device__ __forceinline__ void stage_velocity(float* lds, const Vel& v, int ox,
 template <bool HALO, class S>
 __device__ __forceinline__ float3 rk4(const S& s, float3 pos, float dt, int& bad, const float3* first)
 {
+    typedef typename S::Arith AR;
     float hdt = 0.5f * dt;
     float3 u1 = first ? *first : s.template vel<HALO>(pos, bad);
-    float3 p1 = make_float3(pos.x - hdt * u1.x, pos.y - hdt * u1.y, pos.z - hdt * u1.z);
+    float3 p1 = make_float3(AR::step(pos.x, hdt, u1.x), AR::step(pos.y, hdt, u1.y), AR::step(pos.z, hdt, u1.z));
     float3 u2 = s.template vel<HALO>(p1, bad);
-    float3 p2 = make_float3(pos.x - hdt * u2.x, pos.y - hdt * u2.y, pos.z - hdt * u2.z);
+    float3 p2 = make_float3(AR::step(pos.x, hdt, u2.x), AR::step(pos.y, hdt, u2.y), AR::step(pos.z, hdt, u2.z));
     float3 u3 = s.template vel<HALO>(p2, bad);
-    float3 p3 = make_float3(pos.x - dt * u3.x, pos.y - dt * u3.y, pos.z - dt * u3.z);
+    float3 p3 = make_float3(AR::step(pos.x, dt, u3.x), AR::step(pos.y, dt, u3.y), AR::step(pos.z, dt, u3.z));
     float3 u4 = s.template vel<HALO>(p3, bad);
     float sx = ((u1.x + 2.0f * u2.x) + 2.0f * u3.x) + u4.x;
     float sy = ((u1.y + 2.0f * u2.y) + 2.0f * u3.y) + u4.y;
@@ -437,7 +451,7 @@ __device__ __forceinline__ float3 backtrace(const S& s, float3 pos, float dt, in
 
 // One advected velocity component at face (i,j,k): Solver.cu:377-400 for dir = DIR.
 template <int DIR, bool MAC, bool HALO, class S>
-__device__ __forceinline__ float advect_component(const S& s, const GlobalSampler& G, int i, int j,
+__device__ __forceinline__ float advect_component(const S& s, const GlobalSampler<typename S::Arith>& G, int i, int j,
                                                   int k, float dt, int& bad)
 {
     float3 pos;   // Solver.cu:381-383
@@ -457,7 +471,7 @@ __device__ __forceinline__ float advect_component(const S& s, const GlobalSample
     const ZRange& zr = DIR == 3 ? G.zf : G.zc;
     if (HALO) bad |= (az.i < zr.chk_lo) | (az.i > zr.chk_hi);
     // the advected field is the component itself (Solver.cu:1153-1155)
-    return gather_global(DIR == 1 ? G.ux : (DIR == 2 ? G.uy : G.uz), ax, ay, az,
+    return gather_global<typename S::Arith>(DIR == 1 ? G.ux : (DIR == 2 ? G.uy : G.uz), ax, ay, az,
                          DIR == 1 ? G.nx + 1 : G.nx, DIR == 2 ? G.ny + 1 : G.ny, zr, G.pitch,
                          G.plane);
 }
@@ -549,7 +563,7 @@ struct DimsNarrow : BrickDims<kBX, kBY, kBZ, 3, 2, 2, 2> { static constexpr int 
 // ux, uy, uz advected from the old velocity, all faces with i < B.x0 + B.nx.  Cell (i,j,k) of
 // the box owns face i of ux (if j < ny, k < zend), face j of uy (if k < zend) and face k of uz
 // (if j < ny); the box spans j in [0, ny] and k in [z0, zend].
-template <class Dims, bool MAC, bool HALO>
+template <class Dims, bool MAC, bool HALO, class AR = Plain>
 __global__ void __launch_bounds__(kThreads, Dims::kWaves)
 k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* __restrict__ nuz, Vel v,
                       float dt, Box B, int zend, int* halo_flag)
@@ -558,7 +572,7 @@ k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* _
     int bx, by, bz;
     brick_of_block(B, bx, by, bz);
     const int X0 = B.x0 + bx * kBX, Y0 = B.y0 + by * kBY, Z0 = B.z0 + bz * kBZ;
-    BrickSampler<Dims> S;
+    BrickSampler<Dims, AR> S;
     S.G.init(v);
     S.lds = lds;
     S.set_origin(X0 - Dims::HXL, Y0 - Dims::HY, Z0 - Dims::HZ);
@@ -584,7 +598,7 @@ k_advect_velocity_lds(float* __restrict__ nux, float* __restrict__ nuy, float* _
 // Solver.cu:381-383 with dir = 0, and same velocity, Solver.cu:1160-1164).  With DIV the kernel
 // also writes the divergence of that velocity (Solver.cu:406-423) for its cells, straight from
 // the staged bricks: the projection that follows then needs no separate pass over the velocity.
-template <class Dims, bool MAC, bool HALO, bool DIV>
+template <class Dims, bool MAC, bool HALO, bool DIV, class AR = Plain>
 __global__ void __launch_bounds__(kThreads, Dims::kWaves)
 k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const float* __restrict__ rho,
                      float* __restrict__ nrho, float* __restrict__ div, Vel v, float dt, Box B,
@@ -594,7 +608,7 @@ k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const 
     int bx, by, bz;
     brick_of_block(B, bx, by, bz);
     const int X0 = B.x0 + bx * kBX, Y0 = B.y0 + by * kBY, Z0 = B.z0 + bz * kBZ;
-    BrickSampler<Dims> S;
+    BrickSampler<Dims, AR> S;
     S.G.init(v);
     S.lds = lds;
     S.set_origin(X0 - Dims::HXL, Y0 - Dims::HY, Z0 - Dims::HZ);
@@ -615,8 +629,8 @@ k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const 
         Axis ax = split_axis(c.x - 0.5f), ay = split_axis(c.y - 0.5f), az = split_axis(c.z - 0.5f);
         if (HALO) bad |= (az.i < v.zc.chk_lo) | (az.i > v.zc.chk_hi);
         const int o = i + j * v.pitch + k * v.plane;
-        nT[o] = gather_global(FT, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
-        nrho[o] = gather_global(FR, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+        nT[o] = gather_global<AR>(FT, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+        nrho[o] = gather_global<AR>(FR, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
         if (DIV) {
             const float* q = lds + (i - S.ox) * Dims::SX + (j - S.oy) * Dims::SY + (k - S.oz) * Dims::SZ;
             const float ul = q[0], ur = q[Dims::SX];
@@ -630,7 +644,7 @@ k_advect_scalars_lds(const float* __restrict__ T, float* __restrict__ nT, const 
 
 // Global-path kernel for one velocity component over an arbitrary box of faces (used for the
 // faces the brick kernel does not cover, and for A/B timing): TX x TY x TZ threads, one face each.
-template <int DIR, bool MAC, bool HALO, int TX, int TY, int TZ>
+template <int DIR, bool MAC, bool HALO, int TX, int TY, int TZ, class AR = Plain>
 __global__ void __launch_bounds__(TX * TY * TZ)
 k_advect_component_global(float* __restrict__ out, Vel v, float dt, Box B, int* halo_flag)
 {
@@ -640,14 +654,14 @@ k_advect_component_global(float* __restrict__ out, Vel v, float dt, Box B, int* 
     const int x = bx * TX + t % TX, y = by * TY + (t / TX) % TY, z = bz * TZ + t / (TX * TY);
     if (x >= B.nx || y >= B.ny || z >= B.nz) return;
     const int i = B.x0 + x, j = B.y0 + y, k = B.z0 + z;
-    GlobalSampler G;
+    GlobalSampler<AR> G;
     G.init(v);
     int bad = 0;
     out[i + j * v.pitch + k * v.plane] = advect_component<DIR, MAC, HALO>(G, G, i, j, k, dt, bad);
     if (HALO && bad) atomicOr(halo_flag, 1);
 }
 
-template <bool MAC, bool HALO, int TX, int TY, int TZ>
+template <bool MAC, bool HALO, int TX, int TY, int TZ, class AR = Plain>
 __global__ void __launch_bounds__(TX * TY * TZ)
 k_advect_scalars_global(const float* __restrict__ T, float* __restrict__ nT,
                         const float* __restrict__ rho, float* __restrict__ nrho, Vel v, float dt, Box B,
@@ -659,7 +673,7 @@ k_advect_scalars_global(const float* __restrict__ T, float* __restrict__ nT,
     const int x = bx * TX + t % TX, y = by * TY + (t / TX) % TY, z = bz * TZ + t / (TX * TY);
     if (x >= B.nx || y >= B.ny || z >= B.nz) return;
     const int i = B.x0 + x, j = B.y0 + y, k = B.z0 + z;
-    GlobalSampler G;
+    GlobalSampler<AR> G;
     G.init(v);
     const Fld FT = make_fld(T, v.zc, v.pitch, v.plane), FR = make_fld(rho, v.zc, v.pitch, v.plane);
     int bad = 0;
@@ -668,8 +682,8 @@ k_advect_scalars_global(const float* __restrict__ T, float* __restrict__ nT,
     Axis ax = split_axis(c.x - 0.5f), ay = split_axis(c.y - 0.5f), az = split_axis(c.z - 0.5f);
     if (HALO) bad |= (az.i < v.zc.chk_lo) | (az.i > v.zc.chk_hi);
     const int o = i + j * v.pitch + k * v.plane;
-    nT[o] = gather_global(FT, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
-    nrho[o] = gather_global(FR, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+    nT[o] = gather_global<AR>(FT, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
+    nrho[o] = gather_global<AR>(FR, ax, ay, az, v.nx, v.ny, v.zc, v.pitch, v.plane);
     if (HALO && bad) atomicOr(halo_flag, 1);
 }
 
@@ -679,33 +693,41 @@ bool narrow_brick(const FsGrid& g) { return g.env.advect_brick != 0; }
 bool use_global_path(const FsGrid& g) { return (g.env.advect_global & 1) != 0; }
 bool scalars_use_lds(const FsGrid& g) { return (g.env.advect_global & 2) == 0; }
 
-#define FS_DISPATCH_MH(mac, halo, CALL)   \
-    do {                                  \
-        if (mac && halo) CALL(true, true);    \
-        else if (mac) CALL(true, false);      \
-        else if (halo) CALL(false, true);     \
-        else CALL(false, false);              \
+// CALL(M, H, AR) with the run-time scheme, slab and arithmetic choices as template arguments
+#define FS_DISPATCH_MH(mac, halo, fmad, CALL)      \
+    do {                                           \
+        if (fmad) {                                \
+            if (mac && halo) CALL(true, true, Fused);        \
+            else if (mac) CALL(true, false, Fused);          \
+            else if (halo) CALL(false, true, Fused);         \
+            else CALL(false, false, Fused);                  \
+        } else {                                   \
+            if (mac && halo) CALL(true, true, Plain);        \
+            else if (mac) CALL(true, false, Plain);          \
+            else if (halo) CALL(false, true, Plain);         \
+            else CALL(false, false, Plain);                  \
+        }                                          \
     } while (0)
 
 template <int DIR>
-void launch_component_global(hipStream_t st, float* out, const Vel& v, float dt, bool mac, bool halo,
+void launch_component_global(hipStream_t st, float* out, const Vel& v, float dt, bool mac, bool halo, bool fmad,
                              int x0, int y0, int z0, int nx, int ny, int nz, bool thin_x,
                              int* halo_flag)
 {
     if (nx <= 0 || ny <= 0 || nz <= 0) return;
     if (thin_x) {
         Box B = make_box(1, 64, 4, x0, y0, z0, nx, ny, nz);
-#define FS_CALL(M, H)                                                                          \
-    hipLaunchKernelGGL((k_advect_component_global<DIR, M, H, 1, 64, 4>), dim3(B.nb), dim3(256), 0, st, \
+#define FS_CALL(M, H, AR)                                                                          \
+    hipLaunchKernelGGL((k_advect_component_global<DIR, M, H, 1, 64, 4, AR>), dim3(B.nb), dim3(256), 0, st, \
                        out, v, dt, B, halo_flag)
-        FS_DISPATCH_MH(mac, halo, FS_CALL);
+        FS_DISPATCH_MH(mac, halo, fmad, FS_CALL);
 #undef FS_CALL
     } else {
         Box B = make_box(64, 4, 1, x0, y0, z0, nx, ny, nz);
-#define FS_CALL(M, H)                                                                          \
-    hipLaunchKernelGGL((k_advect_component_global<DIR, M, H, 64, 4, 1>), dim3(B.nb), dim3(256), 0, st, \
+#define FS_CALL(M, H, AR)                                                                          \
+    hipLaunchKernelGGL((k_advect_component_global<DIR, M, H, 64, 4, 1, AR>), dim3(B.nb), dim3(256), 0, st, \
                        out, v, dt, B, halo_flag)
-        FS_DISPATCH_MH(mac, halo, FS_CALL);
+        FS_DISPATCH_MH(mac, halo, fmad, FS_CALL);
 #undef FS_CALL
     }
 }
@@ -727,30 +749,30 @@ void advect_velocity(hipStream_t st, const FsGrid& g, float* nux, float* nuy, fl
     }
     if (ze <= zb) return;
     Vel v = make_vel(g, ux, uy, uz, owned_only);
-    const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0;
+    const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0, fmad = g.fmad != 0;
     const ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
     float *ox = nux - zoff, *oy = nuy - zoff, *oz = nuz - zoff;
     const int nzc = min(ze, zend) - zb;   // planes of [zb, ze) that hold ux / uy faces
     if (use_global_path(g)) {
-        launch_component_global<1>(st, ox, v, dt, mac, halo, 0, 0, zb, g.nx + 1, g.ny, nzc, false, halo_flag);
-        launch_component_global<2>(st, oy, v, dt, mac, halo, 0, 0, zb, g.nx, g.ny + 1, nzc, false, halo_flag);
-        launch_component_global<3>(st, oz, v, dt, mac, halo, 0, 0, zb, g.nx, g.ny, ze - zb, false, halo_flag);
+        launch_component_global<1>(st, ox, v, dt, mac, halo, fmad, 0, 0, zb, g.nx + 1, g.ny, nzc, false, halo_flag);
+        launch_component_global<2>(st, oy, v, dt, mac, halo, fmad, 0, 0, zb, g.nx, g.ny + 1, nzc, false, halo_flag);
+        launch_component_global<3>(st, oz, v, dt, mac, halo, fmad, 0, 0, zb, g.nx, g.ny, ze - zb, false, halo_flag);
         return;
     }
     // brick kernel: all faces with i < nx; the ux faces at i = nx go through the global path
     Box B = make_box(kBX, kBY, kBZ, 0, 0, zb, g.nx, g.ny + 1, ze - zb);
-#define FS_CALL(M, H)                                                                              \
+#define FS_CALL(M, H, AR)                                                                          \
     do {                                                                                           \
-        if (narrow_brick(g))                                                                        \
-            hipLaunchKernelGGL((k_advect_velocity_lds<DimsNarrow, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
+        if (narrow_brick(g))                                                                       \
+            hipLaunchKernelGGL((k_advect_velocity_lds<DimsNarrow, M, H, AR>), dim3(B.nb), dim3(kThreads), 0, st, \
                                ox, oy, oz, v, dt, B, zend, halo_flag);                             \
         else                                                                                       \
-            hipLaunchKernelGGL((k_advect_velocity_lds<DimsWide, M, H>), dim3(B.nb), dim3(kThreads), 0, st, \
+            hipLaunchKernelGGL((k_advect_velocity_lds<DimsWide, M, H, AR>), dim3(B.nb), dim3(kThreads), 0, st, \
                                ox, oy, oz, v, dt, B, zend, halo_flag);                             \
     } while (0)
-    FS_DISPATCH_MH(mac, halo, FS_CALL);
+    FS_DISPATCH_MH(mac, halo, fmad, FS_CALL);
 #undef FS_CALL
-    launch_component_global<1>(st, ox, v, dt, mac, halo, g.nx, 0, zb, 1, g.ny, nzc, true, halo_flag);
+    launch_component_global<1>(st, ox, v, dt, mac, halo, fmad, g.nx, 0, zb, 1, g.ny, nzc, true, halo_flag);
 }
 
 bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, const float* rho,
@@ -763,33 +785,33 @@ bool advect_scalars(hipStream_t st, const FsGrid& g, const float* T, float* nT, 
     }
     if (ze <= zb) return div != nullptr && scalars_use_lds(g);
     Vel v = make_vel(g, ux, uy, uz, owned_only);
-    const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0;
+    const bool halo = !(g.wall_lo && g.wall_hi), mac = scheme != 0, fmad = g.fmad != 0;
     const ptrdiff_t zoff = (ptrdiff_t)g.z0 * g.plane;
     if (!scalars_use_lds(g)) {
         Box B = make_box(64, 4, 1, 0, 0, zb, g.nx, g.ny, ze - zb);
-#define FS_CALL(M, H)                                                                             \
-    hipLaunchKernelGGL((k_advect_scalars_global<M, H, 64, 4, 1>), dim3(B.nb), dim3(256), 0, st,   \
+#define FS_CALL(M, H, AR)                                                                         \
+    hipLaunchKernelGGL((k_advect_scalars_global<M, H, 64, 4, 1, AR>), dim3(B.nb), dim3(256), 0, st, \
                        T - zoff, nT - zoff, rho - zoff, nrho - zoff, v, dt, B, halo_flag)
-        FS_DISPATCH_MH(mac, halo, FS_CALL);
+        FS_DISPATCH_MH(mac, halo, fmad, FS_CALL);
 #undef FS_CALL
         return false;
     }
     Box B = make_box(kBX, kBY, kBZ, 0, 0, zb, g.nx, g.ny, ze - zb);
     float* dv = div ? div - zoff : nullptr;
-#define FS_CALL2(D, M, H, DV)                                                                     \
-    hipLaunchKernelGGL((k_advect_scalars_lds<D, M, H, DV>), dim3(B.nb), dim3(kThreads), 0, st, T - zoff, \
+#define FS_CALL2(D, M, H, DV, AR)                                                                 \
+    hipLaunchKernelGGL((k_advect_scalars_lds<D, M, H, DV, AR>), dim3(B.nb), dim3(kThreads), 0, st, T - zoff, \
                        nT - zoff, rho - zoff, nrho - zoff, dv, v, dt, B, halo_flag)
-#define FS_CALL(M, H)                                                                             \
+#define FS_CALL(M, H, AR)                                                                         \
     do {                                                                                          \
-        if (narrow_brick(g)) {                                                                     \
-            if (dv) FS_CALL2(DimsNarrow, M, H, true);                                             \
-            else FS_CALL2(DimsNarrow, M, H, false);                                               \
+        if (narrow_brick(g)) {                                                                    \
+            if (dv) FS_CALL2(DimsNarrow, M, H, true, AR);                                         \
+            else FS_CALL2(DimsNarrow, M, H, false, AR);                                           \
         } else {                                                                                  \
-            if (dv) FS_CALL2(DimsWide, M, H, true);                                               \
-            else FS_CALL2(DimsWide, M, H, false);                                                 \
+            if (dv) FS_CALL2(DimsWide, M, H, true, AR);                                           \
+            else FS_CALL2(DimsWide, M, H, false, AR);                                             \
         }                                                                                         \
     } while (0)
-    FS_DISPATCH_MH(mac, halo, FS_CALL);
+    FS_DISPATCH_MH(mac, halo, fmad, FS_CALL);
 #undef FS_CALL
 #undef FS_CALL2
     return dv != nullptr;

@@ -54,6 +54,8 @@ struct FsGrid {
     int jacobi_deep;      // 1 = a single domain runs its sweeps in passes of six where it can
     int jacobi_deep_lz;   // planes per z chunk of a six-sweep pass, 0 = by the cost model
     int jacobi_deep_nt;   // 1 = the six-sweep passes store with the non-temporal policy
+    int fmad;         // 1 = FS_FLAG_FMAD: the advection, the buoyancy and the confinement gathers fuse their
+                      // multiply-adds the way a contracting compiler does (see fs_advect.hip)
     FsEnv env;        // the environment switches as they stood when the solver was created
 };
 

@@ -57,6 +57,15 @@ __global__ void k_source(float* __restrict__ rho, float* __restrict__ T, FsSourc
 // Solver.cu:346-368 (BURST off).  The gather point (i+.5, j, k+.5) has x and z weights
 // exactly 0 and y weight exactly .5, so for finite T the clamped trilinear gather equals
 // T(i,clamp(j-1),k)*.5 + T(i,clamp(j),k)*.5 with the same roundings (a*1 + b*0 == a).
+// FMAD: lerp's left product and the final multiply-add fused (FS_FLAG_FMAD).
+template <bool FMAD>
+__device__ __forceinline__ float buoyant(float uy, float a, float c, float dt, float T_env)
+{
+    if constexpr (FMAD) return __builtin_fmaf(__builtin_fmaf(a, 1.0f - 0.5f, c * 0.5f) - T_env, dt, uy);
+    else return uy + (a * (1.0f - 0.5f) + c * 0.5f - T_env) * dt;
+}
+
+template <bool FMAD>
 __global__ void k_force(float* __restrict__ uy, const float* __restrict__ T, float dt, float T_env,
                         int nx, int ny, int pitch, int plane)
 {
@@ -69,12 +78,11 @@ __global__ void k_force(float* __restrict__ uy, const float* __restrict__ T, flo
     int zo = z * plane + x;
     float a = T[zo + jm * pitch];
     float c = T[zo + jp * pitch];
-    float t = a * (1.0f - 0.5f) + c * 0.5f;
-    float buoyancy = (t - T_env) * dt;
-    uy[zo + j * pitch] += buoyancy;
+    uy[zo + j * pitch] = buoyant<FMAD>(uy[zo + j * pitch], a, c, dt, T_env);
 }
 
 // the same for four faces along x per thread (nx % 4 == 0; rows are 64-byte aligned)
+template <bool FMAD>
 __global__ void k_force4(float* __restrict__ uy, const float* __restrict__ T, float dt, float T_env,
                          int nx4, int ny, int pitch, int plane)
 {
@@ -90,10 +98,10 @@ __global__ void k_force4(float* __restrict__ uy, const float* __restrict__ T, fl
     const f4 c = *(const f4*)(T + zo + jp * pitch);
     f4* dst = (f4*)(uy + zo + j * pitch);
     f4 u = *dst;
-    u.x += (a.x * (1.0f - 0.5f) + c.x * 0.5f - T_env) * dt;
-    u.y += (a.y * (1.0f - 0.5f) + c.y * 0.5f - T_env) * dt;
-    u.z += (a.z * (1.0f - 0.5f) + c.z * 0.5f - T_env) * dt;
-    u.w += (a.w * (1.0f - 0.5f) + c.w * 0.5f - T_env) * dt;
+    u.x = buoyant<FMAD>(u.x, a.x, c.x, dt, T_env);
+    u.y = buoyant<FMAD>(u.y, a.y, c.y, dt, T_env);
+    u.z = buoyant<FMAD>(u.z, a.z, c.z, dt, T_env);
+    u.w = buoyant<FMAD>(u.w, a.w, c.w, dt, T_env);
     *dst = u;
 }
 
@@ -304,12 +312,17 @@ void source(hipStream_t st, const FsGrid& g, const FsSource& src, float* rho, fl
 
 void force_uy(hipStream_t st, const FsGrid& g, float* uy, const float* T, float dt, float T_env)
 {
-    if (g.nx % 4 == 0)
-        hipLaunchKernelGGL(k_force4, tile_grid(g.nx / 4, g.ny + 1, g.nzl), kTile, 0, st, uy, T, dt, T_env,
-                           g.nx / 4, g.ny, g.pitch, g.plane);
-    else
-        hipLaunchKernelGGL(k_force, tile_grid(g.nx, g.ny + 1, g.nzl), kTile, 0, st, uy, T, dt, T_env,
-                           g.nx, g.ny, g.pitch, g.plane);
+    if (g.nx % 4 == 0) {
+        if (g.fmad) hipLaunchKernelGGL(k_force4<true>, tile_grid(g.nx / 4, g.ny + 1, g.nzl), kTile, 0, st, uy, T, dt,
+                                       T_env, g.nx / 4, g.ny, g.pitch, g.plane);
+        else hipLaunchKernelGGL(k_force4<false>, tile_grid(g.nx / 4, g.ny + 1, g.nzl), kTile, 0, st, uy, T, dt, T_env,
+                                g.nx / 4, g.ny, g.pitch, g.plane);
+    } else {
+        if (g.fmad) hipLaunchKernelGGL(k_force<true>, tile_grid(g.nx, g.ny + 1, g.nzl), kTile, 0, st, uy, T, dt, T_env,
+                                       g.nx, g.ny, g.pitch, g.plane);
+        else hipLaunchKernelGGL(k_force<false>, tile_grid(g.nx, g.ny + 1, g.nzl), kTile, 0, st, uy, T, dt, T_env,
+                                g.nx, g.ny, g.pitch, g.plane);
+    }
 }
 
 void divergence(hipStream_t st, const FsGrid& g, float* div, const float* ux, const float* uy,

@@ -167,6 +167,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     s->xctx = ctx;
     FsGrid& g = s->g;
     g.env = env;
+    g.fmad = (p->flags & FS_FLAG_FMAD) ? 1 : 0;
     g.nx = p->nx;
     g.ny = p->ny;
     g.nz = p->nz;

@@ -92,12 +92,15 @@ __device__ __forceinline__ VortTaps make_taps(const VortView& v, int i, int j, i
 }
 
 // lerp(a, b, s) = a*(1-s) + b*s (Math.cuh:57-60) for the two weights that occur here.  With s = 0
-// the result is a for every finite b (a*1 + b*0), so b is not loaded.
-template <bool HALF>
+// the result is a for every finite b (a*1 + b*0), so b is not loaded.  FM: the left product fused into
+// the sum, what a contracting compiler makes of the expression (FS_FLAG_FMAD; the halves are exact
+// for normal numbers, so the two forms differ for subnormal operands only).
+template <bool HALF, bool FM>
 __device__ __forceinline__ float lerp_s(float a, float b)
 {
-    if constexpr (HALF) return a * (1.0f - 0.5f) + b * 0.5f;
-    else return a;
+    if constexpr (!HALF) return a;
+    else if constexpr (FM) return __builtin_fmaf(a, 1.0f - 0.5f, b * 0.5f);
+    else return a * (1.0f - 0.5f) + b * 0.5f;
 }
 
 // trilerp (Solver.cu:52-113, clamped samples) at a point whose coordinates, after the array's
@@ -105,7 +108,7 @@ __device__ __forceinline__ float lerp_s(float a, float b)
 // positive, so int() and floor() agree, the lower tap is i + floor(H/2) and the weight is 0 or
 // one half according to the parity of H -- both known at compile time.  Identical taps of
 // different gathers are loaded once (same address expression, no store in between).
-template <int HX, int HY, int HZ>
+template <int HX, int HY, int HZ, bool FM>
 __device__ __forceinline__ float gather(const VortView& v, const VortTaps& t)
 {
     constexpr int ox = (HX >> 1) + 1, oy = (HY >> 1) + 1, oz = (HZ >> 1) + 1;   // 0..2, arithmetic shift = floor
@@ -113,42 +116,42 @@ __device__ __forceinline__ float gather(const VortView& v, const VortTaps& t)
     static_assert(ox >= 0 && ox + fx <= 2 && oy >= 0 && oy + fy <= 2 && oz >= 0 && oz + fz <= 2, "tap range");
     auto tap = [&](int a, int b, int c) { return v.f[t.x[a] + t.y[b] + t.z[c]]; };
     auto row = [&](int b, int c) {
-        if constexpr (fx) return lerp_s<true>(tap(ox, b, c), tap(ox + 1, b, c));
+        if constexpr (fx) return lerp_s<true, FM>(tap(ox, b, c), tap(ox + 1, b, c));
         else return tap(ox, b, c);
     };
     auto slab = [&](int c) {
-        if constexpr (fy) return lerp_s<true>(row(oy, c), row(oy + 1, c));
+        if constexpr (fy) return lerp_s<true, FM>(row(oy, c), row(oy + 1, c));
         else return row(oy, c);
     };
-    if constexpr (fz) return lerp_s<true>(slab(oz), slab(oz + 1));
+    if constexpr (fz) return lerp_s<true, FM>(slab(oz), slab(oz + 1));
     else return slab(oz);
 }
 
 // |omega| at face position + (DX,DY,DZ)/2, Solver.cu:556-584.  PX,PY,PZ: twice the face's
 // staggering (0 on the component's own axis, 1 elsewhere); the arrays are staggered by one half
 // along x (vortx), y (vorty), z (vortz).
-template <int PX, int PY, int PZ, int DX, int DY, int DZ>
+template <int PX, int PY, int PZ, int DX, int DY, int DZ, bool FM>
 __device__ __forceinline__ void vort3(const VortView& vx, const VortTaps& tx, const VortView& vy,
                                       const VortTaps& ty, const VortView& vz, const VortTaps& tz,
                                       float& ox, float& oy, float& oz)
 {
-    ox = gather<PX + DX - 1, PY + DY, PZ + DZ>(vx, tx);
-    oy = gather<PX + DX, PY + DY - 1, PZ + DZ>(vy, ty);
-    oz = gather<PX + DX, PY + DY, PZ + DZ - 1>(vz, tz);
+    ox = gather<PX + DX - 1, PY + DY, PZ + DZ, FM>(vx, tx);
+    oy = gather<PX + DX, PY + DY - 1, PZ + DZ, FM>(vy, ty);
+    oz = gather<PX + DX, PY + DY, PZ + DZ - 1, FM>(vz, tz);
 }
 
-template <int PX, int PY, int PZ, int DX, int DY, int DZ>
+template <int PX, int PY, int PZ, int DX, int DY, int DZ, bool FM>
 __device__ __forceinline__ float vort_norm(const VortView& vx, const VortTaps& tx, const VortView& vy,
                                            const VortTaps& ty, const VortView& vz, const VortTaps& tz)
 {
     float a, b, c;
-    vort3<PX, PY, PZ, DX, DY, DZ>(vx, tx, vy, ty, vz, tz, a, b, c);
+    vort3<PX, PY, PZ, DX, DY, DZ, FM>(vx, tx, vy, ty, vz, tz, a, b, c);
     return sqrtf(a * a + b * b + c * c);
 }
 
 // Solver.cu:540-605 for component DIR (1: ux, 2: uy, 3: uz); (dx,dy,dz) are the dims of that
 // component, which are also the reference's launch dims, so the guard of :548 is literal.
-template <int DIR>
+template <int DIR, bool FM>
 __global__ void k_vort_confine(float* __restrict__ u, VortView vx, VortView vy, VortView vz, int dx, int dy,
                                int dz, int pitch, int plane, float coeff, int zb)
 {
@@ -159,14 +162,14 @@ __global__ void k_vort_confine(float* __restrict__ u, VortView vx, VortView vy, 
     constexpr int PX = DIR == 1 ? 0 : 1, PY = DIR == 2 ? 0 : 1, PZ = DIR == 3 ? 0 : 1;
     const VortTaps tx = make_taps(vx, i, j, k), ty = make_taps(vy, i, j, k), tz = make_taps(vz, i, j, k);
 
-    const float vt = vort_norm<PX, PY, PZ, 0, 1, 0>(vx, tx, vy, ty, vz, tz);
-    const float vbo = vort_norm<PX, PY, PZ, 0, -1, 0>(vx, tx, vy, ty, vz, tz);
-    const float vr = vort_norm<PX, PY, PZ, 1, 0, 0>(vx, tx, vy, ty, vz, tz);
-    const float vl = vort_norm<PX, PY, PZ, -1, 0, 0>(vx, tx, vy, ty, vz, tz);
-    const float vf = vort_norm<PX, PY, PZ, 0, 0, 1>(vx, tx, vy, ty, vz, tz);
-    const float vbh = vort_norm<PX, PY, PZ, 0, 0, -1>(vx, tx, vy, ty, vz, tz);
+    const float vt = vort_norm<PX, PY, PZ, 0, 1, 0, FM>(vx, tx, vy, ty, vz, tz);
+    const float vbo = vort_norm<PX, PY, PZ, 0, -1, 0, FM>(vx, tx, vy, ty, vz, tz);
+    const float vr = vort_norm<PX, PY, PZ, 1, 0, 0, FM>(vx, tx, vy, ty, vz, tz);
+    const float vl = vort_norm<PX, PY, PZ, -1, 0, 0, FM>(vx, tx, vy, ty, vz, tz);
+    const float vf = vort_norm<PX, PY, PZ, 0, 0, 1, FM>(vx, tx, vy, ty, vz, tz);
+    const float vbh = vort_norm<PX, PY, PZ, 0, 0, -1, FM>(vx, tx, vy, ty, vz, tz);
     float vxc, vyc, vzc;
-    vort3<PX, PY, PZ, 0, 0, 0>(vx, tx, vy, ty, vz, tz, vxc, vyc, vzc);
+    vort3<PX, PY, PZ, 0, 0, 0, FM>(vx, tx, vy, ty, vz, tz, vxc, vyc, vzc);
 
     float gx = vr - vl;
     float gy = vt - vbo;
@@ -202,6 +205,7 @@ struct Lattice {
     }
 };
 
+template <bool FM>
 __global__ void k_vort_lattice(Lattice Lt, VortView vx, VortView vy, VortView vz, int nx, int ny, int kb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -211,10 +215,10 @@ __global__ void k_vort_lattice(Lattice Lt, VortView vx, VortView vy, VortView vz
     const VortTaps tx = make_taps(vx, i, j, k), ty = make_taps(vy, i, j, k), tz = make_taps(vz, i, j, k);
     const size_t o = Lt.at(i, j, k);
     // (P + D of vort_norm is twice the point's offset from (i, j, k))
-    Lt.A[o] = vort_norm<0, 1, 1, 1, 0, 0>(vx, tx, vy, ty, vz, tz);
-    Lt.B[o] = vort_norm<0, 1, 1, 0, -1, 0>(vx, tx, vy, ty, vz, tz);
-    Lt.C[o] = vort_norm<0, 1, 1, 0, 0, -1>(vx, tx, vy, ty, vz, tz);
-    Lt.D[o] = vort_norm<1, 0, 1, 0, 0, -1>(vx, tx, vy, ty, vz, tz);
+    Lt.A[o] = vort_norm<0, 1, 1, 1, 0, 0, FM>(vx, tx, vy, ty, vz, tz);
+    Lt.B[o] = vort_norm<0, 1, 1, 0, -1, 0, FM>(vx, tx, vy, ty, vz, tz);
+    Lt.C[o] = vort_norm<0, 1, 1, 0, 0, -1, FM>(vx, tx, vy, ty, vz, tz);
+    Lt.D[o] = vort_norm<1, 0, 1, 0, 0, -1, FM>(vx, tx, vy, ty, vz, tz);
 }
 
 // Solver.cu:586-604 for one face from its six |omega| and the vorticity at the face itself
@@ -238,6 +242,7 @@ __device__ __forceinline__ void confine_face(float* dst, float coeff, float vr, 
 // All three components of the faces (i, j, k), k in [kb, kb + gridDim.z); the guards are those of the
 // reference's three launches (:548 with each component's own dims); kxy_end: first plane without ux
 // and uy faces of this rank (the shared uz face plane of a slab has none)
+template <bool FM>
 __global__ void k_vort_confine_all(float* __restrict__ ux, float* __restrict__ uy, float* __restrict__ uz, Lattice Lt,
                                    VortView vx, VortView vy, VortView vz, int nx, int ny, int nz, int pitch, int plane,
                                    float coeff, int kb, int kxy_end)
@@ -251,15 +256,15 @@ __global__ void k_vort_confine_all(float* __restrict__ ux, float* __restrict__ u
     const int off = i + j * pitch + k * plane;
     float a, b, c;
     if (k < kxy_end && i < nx + 1 - 2 && j < ny - 2 && k < nz - 2) {          // ux: dims (nx+1, ny, nz)
-        vort3<0, 1, 1, 0, 0, 0>(vx, tx, vy, ty, vz, tz, a, b, c);
+        vort3<0, 1, 1, 0, 0, 0, FM>(vx, tx, vy, ty, vz, tz, a, b, c);
         confine_face<1>(ux + off, coeff, Lt.A[o], Lt.A[o - 1], Lt.B[o + Lt.sx], Lt.B[o], Lt.C[o + Lt.sxy], Lt.C[o], a, b, c);
     }
     if (k < kxy_end && i < nx - 2 && j < ny + 1 - 2 && k < nz - 2) {          // uy: dims (nx, ny+1, nz)
-        vort3<1, 0, 1, 0, 0, 0>(vx, tx, vy, ty, vz, tz, a, b, c);
+        vort3<1, 0, 1, 0, 0, 0, FM>(vx, tx, vy, ty, vz, tz, a, b, c);
         confine_face<2>(uy + off, coeff, Lt.B[o + 1], Lt.B[o], Lt.A[o], Lt.A[o - Lt.sx], Lt.D[o + Lt.sxy], Lt.D[o], a, b, c);
     }
     if (i < nx - 2 && j < ny - 2 && k < nz + 1 - 2) {                          // uz: dims (nx, ny, nz+1)
-        vort3<1, 1, 0, 0, 0, 0>(vx, tx, vy, ty, vz, tz, a, b, c);
+        vort3<1, 1, 0, 0, 0, 0, FM>(vx, tx, vy, ty, vz, tz, a, b, c);
         confine_face<3>(uz + off, coeff, Lt.C[o + 1], Lt.C[o], Lt.D[o + Lt.sx], Lt.D[o], Lt.A[o], Lt.A[o - Lt.sxy], a, b, c);
     }
 }
@@ -340,28 +345,29 @@ void vort_confine(hipStream_t st, const FsGrid& g, float* ux, float* uy, float* 
         // faces with k in [3, nz - 2] read lattice planes k - 1 .. k + 1 (k + 1: ux and uy faces only)
         const int lb = max(kb, 2), le = min(ke, g.nz);
         if (le > lb)
-            hipLaunchKernelGGL(k_vort_lattice, dim3(cdiv(g.nx + 1, 64), cdiv(g.ny + 1, 4), le - lb), block, 0, st, Lt, vx,
-                               vy, vz, g.nx, g.ny, lb);
+            hipLaunchKernelGGL(g.fmad ? k_vort_lattice<true> : k_vort_lattice<false>,
+                               dim3(cdiv(g.nx + 1, 64), cdiv(g.ny + 1, 4), le - lb), block, 0, st, Lt, vx, vy, vz, g.nx, g.ny, lb);
         const int fb = max(g.z0, 3), fe = min(g.z0 + g.nzl + 1, g.nz - 1);
         if (fe > fb)
-            hipLaunchKernelGGL(k_vort_confine_all, dim3(cdiv(g.nx + 1, 64), cdiv(g.ny + 1, 4), fe - fb), block, 0, st,
+            hipLaunchKernelGGL(g.fmad ? k_vort_confine_all<true> : k_vort_confine_all<false>,
+                               dim3(cdiv(g.nx + 1, 64), cdiv(g.ny + 1, 4), fe - fb), block, 0, st,
                                ux - zoff, uy - zoff, uz - zoff, Lt, vx, vy, vz, g.nx, g.ny, g.nz, g.pitch, g.plane, coeff,
                                fb, g.z0 + g.nzl);
         return;
     }
     {
         const int dx = g.nx + 1, dy = g.ny, dz = g.nz;
-        hipLaunchKernelGGL(k_vort_confine<1>, dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl), block, 0, st, ux - zoff, vx, vy,
+        hipLaunchKernelGGL((g.fmad ? k_vort_confine<1, true> : k_vort_confine<1, false>), dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl), block, 0, st, ux - zoff, vx, vy,
                            vz, dx, dy, dz, g.pitch, g.plane, coeff, g.z0);
     }
     {
         const int dx = g.nx, dy = g.ny + 1, dz = g.nz;
-        hipLaunchKernelGGL(k_vort_confine<2>, dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl), block, 0, st, uy - zoff, vx, vy,
+        hipLaunchKernelGGL((g.fmad ? k_vort_confine<2, true> : k_vort_confine<2, false>), dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl), block, 0, st, uy - zoff, vx, vy,
                            vz, dx, dy, dz, g.pitch, g.plane, coeff, g.z0);
     }
     {   // the face plane shared with the upper neighbour is produced by both ranks
         const int dx = g.nx, dy = g.ny, dz = g.nz + 1;
-        hipLaunchKernelGGL(k_vort_confine<3>, dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl + 1), block, 0, st, uz - zoff, vx,
+        hipLaunchKernelGGL((g.fmad ? k_vort_confine<3, true> : k_vort_confine<3, false>), dim3(cdiv(dx, 64), cdiv(dy, 4), g.nzl + 1), block, 0, st, uz - zoff, vx,
                            vy, vz, dx, dy, dz, g.pitch, g.plane, coeff, g.z0);
     }
 }

@@ -46,7 +46,7 @@ public:
 	~Solver();
 	Solver(Solver&& other) noexcept
 	    : handle(other.handle), jacobi_iters(other.jacobi_iters), vort_confine(other.vort_confine),
-	      mgpcg(other.mgpcg), curl_strength(other.curl_strength) { other.handle = nullptr; }
+	      mgpcg(other.mgpcg), fmad(other.fmad), curl_strength(other.curl_strength) { other.handle = nullptr; }
 	Solver& operator=(Solver&& other) noexcept;
 	Solver(const Solver&) = delete;
 	Solver& operator=(const Solver&) = delete;
@@ -107,11 +107,16 @@ public:
 	   grid dimension must be a multiple of 8); false = the Jacobi branch it compiles out
 	   (Solver.cu:1178-1189), jacobi_iters sweeps per step */
 	void SetMultigridSolver(bool on) { mgpcg = on; }
+	/* new: true = evaluate the a*b + c shaped expressions of the advection and the buoyancy with
+	   fused multiply-adds, as a contracting build of the reference (nvcc -fmad=true, its default)
+	   does (FS_FLAG_FMAD in fluidsolver.h); false (default) = every product and sum rounded on its own */
+	void SetFusedMultiplyAdd(bool on) { fmad = on; }
 
 private:
 	fs_solver* handle = nullptr;
 	int jacobi_iters = 30;
 	bool vort_confine = true;
 	bool mgpcg = true;
+	bool fmad = false;
 	float curl_strength = 0.1f;
 };

@@ -70,7 +70,18 @@ enum {
        transport: the exchange function is expected to hand send_hi back as recv_lo and send_lo as
        recv_hi), so one process on one GPU can drive the transfers and the stream ordering.  The
        results are NOT those of the decomposed grid; never set it in a real multi-rank run. */
-    FS_FLAG_TEST_SELF_PEER = 1 << 3
+    FS_FLAG_TEST_SELF_PEER = 1 << 3,
+    /* The arithmetic of a contracting build of the reference.  Its binary is built by nvcc, whose
+       default -fmad=true fuses a multiply into a following add; this library's default is the
+       uncontracted meaning of the source text (every product and sum rounded on its own).  With
+       this flag the expressions of the advection, the buoyancy and the confinement gathers that
+       have the shape x*y + z are evaluated with one fused multiply-add, the way an LLVM-based
+       compiler contracts them: lerp (Math.cuh:57-60) as fma(a, 1-s, b*s), the RK position updates
+       (Solver.cu:145, 150, 155) as fma(-c, u, pos), the buoyancy update (Solver.cu:360-361) as
+       fma(T - T_env, dt, uy).  Which products the reference's own binary fuses is not determined by
+       its source; this is one defined member of that family (the two meanings differ by about 1e-4
+       of the field maximum in the density and 1e-3 in the velocity after 100 steps at 64^3). */
+    FS_FLAG_FMAD = 1 << 4
 };
 
 /*

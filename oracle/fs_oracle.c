@@ -78,8 +78,9 @@ static inline float cg_sample(const float* field, i3 pos, i3 max_pos)
    fuses is not determined by the source, so the oracle's contract is the uncontracted meaning
    (g_fmad = 0).  With g_fmad = 1 the expressions of the advection and the buoyancy that have the
    shape x*y + z or z - x*y are evaluated with one fused multiply-add the way LLVM-based compilers
-   contract them (the left product of a sum of two products is the fused one).  No GPU kernel has
-   this mode; tests use it only to measure how far contraction can move the fields. */
+   contract them (the left product of a sum of two products is the fused one).  It is what the
+   library's FS_FLAG_FMAD mode is checked against, and what measures how far contraction can move
+   the fields. */
 static int g_fmad = 0;
 void fso_set_fmad(int on) { g_fmad = on != 0; }
 

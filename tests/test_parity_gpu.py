@@ -648,3 +648,63 @@ def test_headless_program_calls_the_whole_public_class(fs):
         out = subprocess.run([exe, "3", mode, "surface"], check=True, stdout=subprocess.PIPE, timeout=120, text=True).stdout
         m = re.search(r"surface: max\(rho\) before reset ([-0-9.e+]+), nonzero after reset (\d)", out)
         assert m and float(m.group(1)) > 0 and m.group(2) == "0", out
+
+
+@pytest.fixture
+def fused_oracle(oracle):
+    """The oracle with its contraction switch on (fso_set_fmad), switched off again afterwards."""
+    oracle.set_fmad(True)
+    yield oracle
+    oracle.set_fmad(False)
+
+
+@pytest.mark.parametrize("dims", [(21, 13, 17), (32, 24, 16), (65, 33, 9)])
+def test_fused_multiply_add_mode_stages(fs, fused_oracle, dims):
+    """FS_FLAG_FMAD: the buoyancy and the advection (RK4 and MacCormack, LDS bricks and the global
+    path of rough fields, zero-outside walls) with lerp's left product, the RK position updates and
+    the buoyancy update fused, bit for bit against the oracle's contracted mode -- and different from
+    the default mode, so the flag is not a no-op."""
+    oracle = fused_oracle
+    nx, ny, nz = dims
+    for scheme in (0, 1):
+        for kind in ("smooth", "rough"):
+            g, o = make_pair(fs, oracle, nx, ny, nz, scheme=scheme, flags=fs.FS_FLAG_FMAD)
+            plain = fs.Solver(fs.default_params(nx, ny, nz, scheme=scheme)).Initialize()
+            st = random_fields(nx, ny, nz, seed=17 + scheme, vel_scale=6.0)
+            if kind == "smooth":
+                st[0], st[1], st[2] = smooth_velocity(nx, ny, nz)
+            load_state(g, o, st)
+            for f, a in st.items():
+                plain.upload(f, a)
+            for stage in ("force", "advect"):
+                g.stage(stage); o.stage(stage); plain.stage(stage)
+                assert_all_equal(g, o, fields=range(5), what="fused %s %s scheme %d" % (stage, kind, scheme))
+            assert not np.array_equal(g.field(fs.FS_RHO), plain.field(fs.FS_RHO))
+            g.close(); o.close(); plain.close()
+
+
+@pytest.mark.parametrize("shipped", [False, True])
+def test_fused_multiply_add_mode_steps(fs, fused_oracle, shipped):
+    """Whole steps in the contracted arithmetic: the Jacobi configuration bit for bit, the shipped
+    one (MGPCG + vorticity confinement, whose gathers use the same lerp) to the MGPCG bar."""
+    oracle = fused_oracle
+    nx, ny, nz = (32, 32, 24) if shipped else (36, 28, 20)
+    kw = dict(jacobi_iters=12, source_y=8.0, source_radius=5.0)
+    okw = dict(kw)
+    flags = fs.FS_FLAG_FMAD
+    if shipped:
+        kw.update(pressure_solver=fs.FS_PRESSURE_MGPCG)
+        okw.update(pressure_solver=oracle.PRESSURE_MGPCG, vort_confine=1)
+        flags |= fs.FS_FLAG_VORT_CONFINE
+    g = fs.Solver(fs.default_params(nx, ny, nz, flags=flags, **kw)).Initialize()
+    o = oracle.Oracle(oracle.default_params(nx, ny, nz, **okw))
+    st = random_fields(nx, ny, nz, seed=5, vel_scale=1.0)
+    load_state(g, o, st)
+    for step in range(6):
+        g.step(); o.step()
+        for f in range(6):
+            if shipped:
+                assert rel_linf(g.field(f), o.get(f)) <= 1e-5, (step, f)
+            else:
+                assert np.array_equal(g.field(f), o.get(f)), (step, f)
+    g.close(); o.close()

@@ -5,7 +5,7 @@
 
 Every case draws a grid shape (odd extents, extents of 1, multiples of 4 and 8, thin and flat
 grids), a scheme, a sweep count, optional vorticity confinement, the MGPCG solver where the shape
-allows it, a random initial state and a random tile variant / store policy of the pressure kernel,
+allows it, a random initial state and a random tile variant / store policy / pass depth of the pressure kernel,
 steps both sides a few times and compares every field: bit for bit with the Jacobi solver, to 1e-5
 plus equal iteration counts with MGPCG.  Prints one line per failing case and a summary; exit
 status 1 if any case failed.  A complement to the fixed shapes of the test suite, not part of it.
@@ -70,6 +70,10 @@ def main():
         os.environ["FS_JACOBI_CFG"] = str(int(rng.integers(0, 4)))
         os.environ["FS_JACOBI_NT"] = str(int(rng.integers(0, 2)))
         os.environ["FS_JACOBI_TUNE"] = "0"
+        # the six-sweep passes wherever the grid takes them, with short z chunks in half of those cases
+        os.environ["FS_JACOBI_DEEP"] = str(int(rng.integers(0, 2)))
+        os.environ["FS_JACOBI_DEEP_LZ"] = str(int(rng.choice([0, int(rng.integers(3, 40))])))
+        os.environ["FS_JACOBI_DEEP_NT"] = str(int(rng.integers(0, 2)))
         kw = dict(jacobi_iters=k, scheme=scheme, source_y=min(10.0, ny / 3.0), source_radius=min(7.0, min(nx, ny, nz) / 4.0))
         gkw, okw = dict(kw), dict(kw)
         if confine:
@@ -78,8 +82,9 @@ def main():
         if mgpcg:
             gkw["pressure_solver"] = fs.FS_PRESSURE_MGPCG
             okw["pressure_solver"] = oracle.PRESSURE_MGPCG
-        desc = "case %d: %dx%dx%d scheme %d k %d confine %d mgpcg %d steps %d vel %.1f cfg %s nt %s" % (
-            case, nx, ny, nz, scheme, k, confine, mgpcg, steps, vel, os.environ["FS_JACOBI_CFG"], os.environ["FS_JACOBI_NT"])
+        desc = "case %d: %dx%dx%d scheme %d k %d confine %d mgpcg %d steps %d vel %.1f cfg %s nt %s deep %s/%s/%s" % (
+            case, nx, ny, nz, scheme, k, confine, mgpcg, steps, vel, os.environ["FS_JACOBI_CFG"], os.environ["FS_JACOBI_NT"],
+            os.environ["FS_JACOBI_DEEP"], os.environ["FS_JACOBI_DEEP_LZ"], os.environ["FS_JACOBI_DEEP_NT"])
         try:
             g = fs.Solver(fs.default_params(nx, ny, nz, **gkw)).Initialize()
             o = oracle.Oracle(oracle.default_params(nx, ny, nz, **okw))
