@@ -694,8 +694,22 @@ constexpr int kDeepRows = 48;  // its tile rows = rows of threads of a workgroup
 
 bool can_deep(const FsGrid& g) { return can_block(g) && g.ny >= 2 * kTDeep + 2 && g.nzl >= 2 * kTDeep; }
 
-// one pass of kTDeep sweeps over a single domain (both z faces global walls)
-void launch_deep(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div)
+// A z-slab runs six-sweep passes if every rank can (ghost planes six deep, slabs thick enough for two
+// boundary layers of up to 2 kT planes and an interior) and the fields of a rank do not stay in the
+// 256 MiB Infinity Cache -- where they do, the passes are bound by on-chip work and four sweeps per
+// pass win.  Everything this reads is the same on every rank.
+bool deep_slab(const FsGrid& g)
+{
+    if (g.wall_lo && g.wall_hi) return false;
+    if (!can_block(g) || g.ny < 2 * kTDeep + 2 || g.pghost < kTDeep || g.nz_min < 4 * kT + 1) return false;
+    if (g.env.jacobi_deep >= 0) return g.env.jacobi_deep != 0;
+    return (long)g.nx * g.ny >= 224L * 224L && 3L * g.plane * g.nz_min * (long)sizeof(float) > (256L << 20);
+}
+
+// one pass of kTDeep sweeps: reads level-0 planes [zin_lo, zin_hi), writes [zout_lo, zout_hi) and the
+// optional second range (see launch_tb)
+void launch_deep(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
+                 int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo = 0, int zout2_hi = 0)
 {
     constexpr int T = kTDeep, NTY = kDeepRows, BY = NTY - 2 * T;
     TbArgs A;
@@ -706,10 +720,11 @@ void launch_deep(hipStream_t st, const FsGrid& g, const float* p, float* np, con
     A.div = div - zoff;
     A.nx = g.nx; A.ny = g.ny; A.nz = g.nz;
     A.pitch = g.pitch; A.plane = g.plane;
-    A.zin_lo = g.z0; A.zin_hi = g.z0 + g.nzl;
-    A.zout_lo = g.z0; A.zout_hi = g.z0 + g.nzl;
-    A.zout2_lo = A.zout2_hi = 0;
-    const int nout = g.nzl;
+    A.zin_lo = zin_lo; A.zin_hi = zin_hi;
+    A.zout_lo = zout_lo; A.zout_hi = zout_hi;
+    A.zout2_lo = zout2_lo; A.zout2_hi = zout2_hi;
+    const int n1 = zout_hi - zout_lo, n2 = max(0, zout2_hi - zout2_lo);
+    const int nout = n1 + n2;
     const int tiles_x = cdiv(g.nx, tile_bx(1)), tiles_y = max(1, cdiv(g.ny - 2 * T, BY));
     // z chunks: as for k_jacobi_tb, one workgroup per CU
     int chunks = 1;
@@ -726,10 +741,11 @@ void launch_deep(hipStream_t st, const FsGrid& g, const float* p, float* np, con
     A.lz = cdiv(nout, chunks);
     if (g.jacobi_deep_lz > 0) A.lz = min(nout, g.jacobi_deep_lz);
     if (g.env.jacobi_deep_lz > 0) A.lz = min(nout, g.env.jacobi_deep_lz);
-    A.chunks1 = cdiv(nout, A.lz);
+    A.chunks1 = cdiv(n1, A.lz);      // chunks never straddle the two ranges
+    chunks = A.chunks1 + cdiv(n2, A.lz);
     A.tiles_x = tiles_x;
     A.tiles_y = tiles_y;
-    A.nblocks = tiles_x * tiles_y * A.chunks1;
+    A.nblocks = tiles_x * tiles_y * chunks;
     A.order = g.env.jacobi_order;
     dim3 grid(A.nblocks), block(kW4, NTY);
     if (g.env.jacobi_deep_nt >= 0 ? g.env.jacobi_deep_nt != 0 : g.jacobi_deep_nt != 0)
@@ -737,17 +753,27 @@ void launch_deep(hipStream_t st, const FsGrid& g, const float* p, float* np, con
     else hipLaunchKernelGGL((k_jacobi_deep<T, NTY, 0>), grid, block, 0, st, A);
 }
 
+// the same over a single domain (both z faces global walls)
+void launch_deep(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div)
+{
+    launch_deep(st, g, p, np, div, g.z0, g.z0 + g.nzl, g.z0, g.z0 + g.nzl);
+}
+
+// Six-sweep passes among `sweeps` sweeps when the rest runs in passes of `unit` sweeps: as many as
+// leave a remainder such passes take whole, if giving up at most one achieves that; else as many as fit.
+int deep_count(int sweeps, int unit)
+{
+    const int most = sweeps / kTDeep;
+    for (int d = most; d >= 0 && d >= most - 1; --d)
+        if ((sweeps - d * kTDeep) % unit == 0) return d;
+    return most;
+}
+
 // How `sweeps` sweeps are cut into passes of kTDeep and kT sweeps and single sweeps when the deep
-// passes are on: as many deep passes as leave a remainder that passes of kT sweeps take whole, if
-// there is such a split; else deep passes first.
+// passes are on.
 void deep_split(int sweeps, int* deep, int* four, int* single)
 {
-    *deep = sweeps / kTDeep;
-    for (int d = sweeps / kTDeep; d >= 0 && d >= sweeps / kTDeep - 1; --d)
-        if ((sweeps - d * kTDeep) % kT == 0) {
-            *deep = d;
-            break;
-        }
+    *deep = deep_count(sweeps, kT);
     const int left = sweeps - *deep * kTDeep;
     *four = left / kT;
     *single = left % kT;
@@ -877,7 +903,10 @@ void tune_tb(hipStream_t st, FsGrid& g, int nout, const char* what, Pass&& pass,
 
 // Times the six-sweep pass against the four-sweep pass g is set up with (per sweep), over chunk
 // counts and both store policies.
-static void tune_deep(hipStream_t st, FsGrid& g, float* x, float* y, const float* div, int* deep, int* deep_lz, int* deep_nt)
+// [flo, fhi) / [dlo, dhi): the planes a four-sweep / six-sweep pass of this grid produces in one launch
+// (the whole domain, or the interior planes of a slab).
+static void tune_deep(hipStream_t st, FsGrid& g, float* x, float* y, const float* div, int flo, int fhi, int dlo, int dhi,
+                      int* deep, int* deep_lz, int* deep_nt)
 {
     *deep = *deep_lz = *deep_nt = 0;
     hipEvent_t a, b;
@@ -887,7 +916,7 @@ static void tune_deep(hipStream_t st, FsGrid& g, float* x, float* y, const float
         return;
     }
     const bool verbose = g.env.jacobi_tune == 2;
-    const int nout = g.nzl, timed = (long)g.nx * g.ny * nout >= 384L * 384L * 384L ? 3 : 12;
+    const int nout = dhi - dlo, timed = (long)g.nx * g.ny * nout >= 384L * 384L * 384L ? 3 : 12;
     auto time_of = [&](auto&& pass) {
         pass();
         (void)hipEventRecord(a, st);
@@ -898,7 +927,7 @@ static void tune_deep(hipStream_t st, FsGrid& g, float* x, float* y, const float
         return ms / timed;
     };
     const float four = time_of([&] {
-        launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, g.z0, g.z0 + g.nzl);
+        launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, flo, fhi);
         float* t = x; x = y; y = t;
     });
     float best = -1.f;
@@ -910,7 +939,7 @@ static void tune_deep(hipStream_t st, FsGrid& g, float* x, float* y, const float
             g.jacobi_deep_lz = lz;
             g.jacobi_deep_nt = nt;
             const float ms = time_of([&] {
-                launch_deep(st, g, x, y, div);
+                launch_deep(st, g, x, y, div, g.z0, g.z0 + g.nzl, dlo, dhi);
                 float* t = x; x = y; y = t;
             });
             if (verbose) fprintf(stderr, "jacobi_autotune %dx%dx%d: six-sweep pass, %d planes per chunk, nt %d: %.1f us "
@@ -924,9 +953,10 @@ static void tune_deep(hipStream_t st, FsGrid& g, float* x, float* y, const float
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     g.jacobi_deep_lz = g.jacobi_deep_nt = 0;
-    // a sweep of the six-sweep pass has to be cheaper by more than the noise of these readings
-    if (g.env.jacobi_deep == 1 || (best > 0.f && four > 0.f && best / kTDeep < 0.97f * four / kT)) *deep = 1;
-    else *deep_lz = *deep_nt = 0;
+    // a sweep of the six-sweep pass has to be cheaper by more than the noise of these readings (per
+    // plane produced: a slab's six-sweep interior is four planes shorter than its four-sweep one)
+    const float per4 = four / kT / (fhi - flo), per6 = best / kTDeep / (dhi - dlo);
+    *deep = g.env.jacobi_deep == 1 || (best > 0.f && four > 0.f && per6 < 0.97f * per4);
 }
 
 void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float* div)
@@ -935,8 +965,12 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
     g.jacobi_lz = 0;
     g.jacobi_nt = 0;
     g.jacobi_deep = g.jacobi_deep_lz = g.jacobi_deep_nt = 0;
-    // FS_JACOBI_DEEP=1 forces the six-sweep passes wherever they can run (tests), also without timing
-    if (g.env.jacobi_deep == 1 && can_deep(g) && g.wall_lo && g.wall_hi) g.jacobi_deep = 1;
+    // FS_JACOBI_DEEP=1 forces the six-sweep passes wherever they can run (tests), also without timing;
+    // on a slab they are on or off by a rule every rank evaluates alike, and only their chunking and
+    // store policy are timed
+    const bool single = g.wall_lo && g.wall_hi, slab_deep = deep_slab(g);
+    const bool forced = single && g.env.jacobi_deep == 1 && can_deep(g);
+    if (forced || slab_deep) g.jacobi_deep = 1;
     // what a slab's interior launch produces: planes whose T-sweep cone stays inside the owned
     // planes (a pass may only store planes it holds T input planes around, except at a wall)
     const int out_lo = g.z0 + (g.wall_lo ? 0 : kT), out_hi = g.z0 + g.nzl - (g.wall_hi ? 0 : kT);
@@ -955,11 +989,13 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
             launch_tb<kT>(st, g, x, y, div, g.z0, g.z0 + g.nzl, out_lo, out_hi);
             float* t = x; x = y; y = t;
         }, true);
-        // the six-sweep passes (single domain, planes large enough for 64-row tiles): their own
-        // chunking and store policy, then kept if a sweep is cheaper than in the best four-sweep pass
+        // the six-sweep passes (planes large enough for 64-row tiles): their own chunking and store
+        // policy; a single domain then keeps them if a sweep is cheaper than in the best four-sweep pass
         int deep = 0, deep_lz = 0, deep_nt = 0;
-        if (g.env.jacobi_deep != 0 && can_deep(g) && g.wall_lo && g.wall_hi && (long)g.nx * g.ny >= 224L * 224L)
-            tune_deep(st, g, x, y, div, &deep, &deep_lz, &deep_nt);
+        const int dlo = g.z0 + (g.wall_lo ? 0 : kTDeep), dhi = g.z0 + g.nzl - (g.wall_hi ? 0 : kTDeep);
+        if (dhi - dlo >= 2 * kTDeep && (long)g.nx * g.ny >= 224L * 224L &&
+            (single ? g.env.jacobi_deep != 0 && can_deep(g) : slab_deep))
+            tune_deep(st, g, x, y, div, out_lo, out_hi, dlo, dhi, &deep, &deep_lz, &deep_nt);
         it = tuned.emplace(key, std::make_tuple(g.jacobi_tile, g.jacobi_lz, g.jacobi_nt, deep, deep_lz, deep_nt)).first;
     }
     g.jacobi_tile = std::get<0>(it->second);
@@ -968,7 +1004,10 @@ void jacobi_autotune(hipStream_t st, FsGrid& g, float* p, float* np, const float
     g.jacobi_deep = std::get<3>(it->second);
     g.jacobi_deep_lz = std::get<4>(it->second);
     g.jacobi_deep_nt = std::get<5>(it->second);
-    if (g.env.jacobi_deep == 1 && can_deep(g) && g.wall_lo && g.wall_hi) g.jacobi_deep = 1;   // forced (tests)
+    // a slab: the rule decides, whatever this rank's timing said
+    if (forced) g.jacobi_deep = 1;
+    if (!single) g.jacobi_deep = slab_deep ? 1 : 0;
+    if (!g.jacobi_deep) g.jacobi_deep_lz = g.jacobi_deep_nt = 0;
 }
 
 bool jacobi_can_block(const FsGrid& g) { return can_block(g); }
@@ -986,7 +1025,7 @@ void jacobi_config(const FsGrid& g, int* variant, int* rows, int* aligned, int* 
 
 void jacobi_deep_config(const FsGrid& g, int* sweeps_per_pass, int* planes_per_chunk, int* nontemporal)
 {
-    const bool on = g.jacobi_deep && can_deep(g) && g.wall_lo && g.wall_hi;
+    const bool on = g.jacobi_deep && ((g.wall_lo && g.wall_hi) ? can_deep(g) : deep_slab(g));
     *sweeps_per_pass = on ? kTDeep : (can_block(g) ? kT : 1);
     *planes_per_chunk = on ? g.jacobi_deep_lz : 0;
     *nontemporal = on ? g.jacobi_deep_nt : 0;
@@ -1009,6 +1048,25 @@ bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, con
     }
     return true;
 }
+
+bool jacobi_deep_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
+                      int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo, int zout2_hi)
+{
+    if (!can_block(g) || g.ny < 2 * kTDeep + 2) return false;
+    if (zout_hi <= zout_lo) {   // only the second range, or nothing
+        zout_lo = zout2_lo; zout_hi = zout2_hi;
+        zout2_lo = zout2_hi = 0;
+    }
+    if (zout_hi <= zout_lo) return true;
+    launch_deep(st, g, p, np, div, zin_lo, zin_hi, zout_lo, zout_hi, zout2_lo, zout2_hi);
+    return true;
+}
+
+int jacobi_deep_block() { return kTDeep; }
+
+bool jacobi_deep_slab(const FsGrid& g) { return g.jacobi_deep && deep_slab(g); }
+
+int jacobi_deep_count(int sweeps, int unit) { return deep_count(sweeps, unit); }
 
 // Red/black Gauss-Seidel on a dense nx x ny x nz array (rows unpadded): `phases` half-sweeps (2 or 4,
 // red first) from zin into zout; false if this grid cannot take the blocked kernel.

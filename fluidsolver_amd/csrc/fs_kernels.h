@@ -41,6 +41,7 @@ struct FsGrid {
     int nx, ny, nz;   // global cell counts
     int z0;           // global index of the first owned cell plane
     int nzl;          // owned cell planes on this rank
+    int nz_min;       // owned cell planes of the thinnest slab of the decomposition (= nz on a single domain)
     int ghost;        // planes below z0 and above the last owned face plane an advection gather may read
     int pghost;       // ghost planes held per side (>= ghost): what the pressure, its divergence and the
                       // velocity behind that divergence use on a slab
@@ -51,7 +52,7 @@ struct FsGrid {
     int jacobi_tile;  // 1 + tile variant of the blocked Jacobi kernel chosen for this grid, 0 = by rule
     int jacobi_lz;    // planes per z chunk of a blocked pass chosen for this grid, 0 = by the cost model
     int jacobi_nt;    // 1 = the blocked Jacobi passes of this grid store with the non-temporal policy
-    int jacobi_deep;      // 1 = a single domain runs its sweeps in passes of six where it can
+    int jacobi_deep;      // 1 = the sweeps run in passes of six where they can (on a z-slab: the same on every rank)
     int jacobi_deep_lz;   // planes per z chunk of a six-sweep pass, 0 = by the cost model
     int jacobi_deep_nt;   // 1 = the six-sweep passes store with the non-temporal policy
     int fmad;         // 1 = FS_FLAG_FMAD: the advection, the buoyancy and the confinement gathers fuse their
@@ -138,6 +139,18 @@ bool jacobi_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, con
                  int sweeps, int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo = 0,
                  int zout2_hi = 0);
 bool jacobi_can_block(const FsGrid& g);
+// The same with the six-sweep kernel: one pass of jacobi_deep_block() sweeps, zout that many planes
+// inside zin wherever the edge is not a global wall.  False if this grid cannot take the kernel.
+bool jacobi_deep_pass(hipStream_t st, const FsGrid& g, const float* p, float* np, const float* div,
+                      int zin_lo, int zin_hi, int zout_lo, int zout_hi, int zout2_lo = 0, int zout2_hi = 0);
+int jacobi_deep_block();   // sweeps fused per six-sweep pass
+// Whether a z-slab of this decomposition runs six-sweep passes.  Every rank must make the same
+// sequence of exchanges, so this is decided by what all ranks see alike: the grid, the thinnest slab
+// and the environment, never by a rank's own timing.
+bool jacobi_deep_slab(const FsGrid& g);
+// Six-sweep passes among `sweeps` sweeps when the rest runs in passes of `unit` sweeps: as many as
+// leave a multiple of `unit`, if giving up at most one achieves that; else as many as fit.
+int jacobi_deep_count(int sweeps, int unit);
 // Times the tile variants of the blocked kernel on this grid (p, np, div must hold zeros: the
 // passes then leave them zero) and their z chunking, and records the fastest in g.jacobi_tile /
 // g.jacobi_lz.  All variants return the same values, so the choice only affects speed.

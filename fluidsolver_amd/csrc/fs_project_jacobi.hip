@@ -6,7 +6,8 @@
 // need t valid ghost planes of p, because a slab face that is not a global wall loses one plane of
 // validity per sweep.  Each fused pass runs as two launches: first the planes next to each
 // neighbour, whose results then travel to the neighbours' ghost planes while the second launch
-// produces the interior, which needs no ghost plane.
+// produces the interior, which needs no ghost plane.  Slabs whose fields exceed the Infinity Cache
+// run most of their sweeps in passes of six (k_jacobi_deep), the rest in pairs of four-sweep passes.
 #include "fs_solver_impl.h"
 
 #include <cstdio>
@@ -52,6 +53,34 @@ int run_jacobi(fs_solver* s, int sweeps)
         const bool pairs = split && g.pghost >= 2 * T && thinnest >= 6 * T + 1;
         int left = sweeps, launches = 0;
         StageScope sc(s, FS_STAGE_JACOBI, 0);
+        // Six-sweep passes first, where the decomposition runs them: TD valid ghost planes in, the TD
+        // (or more) boundary planes next to each neighbour first, their exchange, the interior.  The
+        // last of them sends as many planes as the pass after it wants valid, so that no pass of the
+        // solve has to wait for an exchange of its own.
+        const int TD = fsk::jacobi_deep_block();
+        const bool deep = split && fsk::jacobi_deep_slab(g);
+        for (int q = deep ? fsk::jacobi_deep_count(sweeps, pairs ? 2 * T : T) : 0; q > 0; --q) {
+            int rc = ensure_p_ghosts(s, TD);
+            if (rc) return rc;
+            const int after = left - TD;
+            const int bw = (q == 1 && pairs && after >= 2 * T) ? 2 * T : TD;
+            const int zin_lo = g.wall_lo ? 0 : g.z0 - TD, zin_hi = g.wall_hi ? g.nz : z1 + TD;
+            const int ilo = g.wall_lo ? g.z0 : g.z0 + bw, ihi = g.wall_hi ? z1 : z1 - bw;
+            FS_TRACE(s, "launch six-sweep Jacobi pass, boundary planes");
+            fsk::jacobi_deep_pass(s->st, g, s->f.p, s->f.np, s->f.div, zin_lo, zin_hi, g.z0, ilo, ihi, z1);
+            xmark(s, s->st, "six-sweep Jacobi pass, boundary planes");
+            Seg seg = make_seg(s, s->f.np, bw, false);
+            rc = exchange_begin(s, &seg, 1);
+            if (rc) return rc;
+            FS_TRACE(s, "launch six-sweep Jacobi pass, interior planes");
+            fsk::jacobi_deep_pass(s->st, g, s->f.p, s->f.np, s->f.div, zin_lo, zin_hi, ilo, ihi);
+            xmark(s, s->st, "six-sweep Jacobi pass, interior planes");
+            std::swap(s->f.p, s->f.np);
+            s->p_ghost = bw;
+            s->prev_held = false;
+            launches += 2;
+            left = after;
+        }
         while (pairs && left >= 2 * T) {
             int rc = ensure_p_ghosts(s, 2 * T);
             if (rc) return rc;

@@ -173,6 +173,7 @@ int create_common(const fs_params* p, int rank, int world, const void* unique_id
     g.nz = p->nz;
     g.z0 = z0;
     g.nzl = nzl;
+    g.nz_min = base;
     g.ghost = ghost;
     g.pghost = pghost;
     g.wall_lo = rank == 0;
@@ -459,7 +460,6 @@ int fs_jacobi_deep_config(const fs_solver* s, int* sweeps_per_pass, int* planes_
     if (!s) return fail(FS_ERR_INVALID, "null solver");
     int t, lz, nt;
     fsk::jacobi_deep_config(s->g, &t, &lz, &nt);
-    if (s->world > 1 && t > fsk::jacobi_block()) t = fsk::jacobi_block();
     if (sweeps_per_pass) *sweeps_per_pass = t;
     if (planes_per_chunk) *planes_per_chunk = lz;
     if (nontemporal_stores) *nontemporal_stores = nt;

@@ -199,6 +199,12 @@ def main():
     p = fs.default_params(nx, ny, nz, device=dev, **kw)
     s = SlabSolver(p, rank, world, transport=mode).Initialize()
     okw = {a: b for a, b in kw.items() if a not in ("flags", "tolerance", "check_every", "max_sweeps")}
+    for word, want in (("deep", 6), ("four", 4)):
+        # the caller expects a decomposition that runs six-sweep (four-sweep) passes: make sure it does
+        if word in extra and s.jacobi_config()["sweeps_per_pass"] != want:
+            print("rank %d: passes of %r sweeps, not %d" % (rank, s.jacobi_config()["sweeps_per_pass"], want))
+            print("SLAB_FAIL")
+            sys.exit(1)
     if "confine" in extra:
         okw["vort_confine"] = 1
     o = oracle.Oracle(oracle.default_params(nx, ny, nz, **okw))

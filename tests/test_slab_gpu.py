@@ -96,6 +96,33 @@ def test_slab_paired_passes_share_one_exchange(world, dims, steps, k, pghost):
               {"FS_SLAB_PGHOST": str(pghost), "FS_JACOBI_TUNE": "0"})
 
 
+@pytest.mark.parametrize("world,dims,steps,k,env", [
+    # 28 planes per rank, 20 sweeps: two six-sweep passes (the second sends 8 planes), one pair of four-sweep passes
+    (2, (72, 52, 56), 2, 20, {}),
+    # interior rank with two neighbours; 26 sweeps: three six-sweep passes and a pair
+    (3, (68, 40, 81), 2, 26, {"FS_JACOBI_TUNE": "0"}),
+    # 19 planes per rank: too thin for pairs; three six-sweep passes and one single sweep, each with its exchange
+    (3, (36, 28, 57), 2, 19, {}),
+    # the sweep count of the benchmark: twelve six-sweep passes and one pair; chunks of 5 planes
+    (2, (64, 100, 64), 1, 80, {"FS_JACOBI_DEEP_LZ": "5", "FS_JACOBI_DEEP_NT": "1"}),
+    # four ranks; 12 sweeps are two six-sweep passes and nothing else
+    (4, (48, 40, 80), 3, 12, {}),
+])
+def test_slab_six_sweep_passes(world, dims, steps, k, env):
+    """FS_JACOBI_DEEP=1 on slabs of at least 17 planes with 8 ghost planes: passes of six sweeps from
+    six valid ghost planes, the boundary planes next to each neighbour first, one exchange per pass
+    hidden behind the interior; the last six-sweep pass sends the 8 planes the pair of four-sweep
+    passes after it wants."""
+    run_ranks(world, ["host", *dims, steps, k, "random", "deep"], 29770 + world + k, dict(env, FS_JACOBI_DEEP="1"))
+
+
+def test_slab_six_sweep_passes_need_thick_slabs_and_deep_ghosts():
+    """Slabs of 16 planes, or ghost planes 4 deep, keep the four-sweep passes whatever the switch says
+    (and still match the oracle)."""
+    run_ranks(2, ["host", 32, 24, 32, 2, 12, "random", "four"], 29768, {"FS_JACOBI_DEEP": "1"})
+    run_ranks(2, ["host", 36, 28, 56, 2, 12, "random", "four"], 29769, {"FS_JACOBI_DEEP": "1", "FS_SLAB_PGHOST": "4"})
+
+
 @pytest.mark.parametrize("lattice", [1, 0])
 @pytest.mark.parametrize("world,dims,steps,k,extra", [
     (2, (24, 20, 32), 4, 8, ["confine"]),
@@ -192,6 +219,12 @@ def test_rccl_send_recv_and_stream_ordering_with_itself_as_neighbour():
     run_ranks(1, ["selfpeer", 64, 48, 24, 12, 20], 29661, {"FS_DEBUG_XCHG": "0"})   # tracing would keep the steps eager
 
 
+def test_rccl_six_sweep_passes_with_itself_as_neighbour():
+    """The same with six-sweep passes (24 planes, 8 ghost planes: two six-sweep passes and two
+    four-sweep passes per step, each with its exchange)."""
+    run_ranks(1, ["selfpeer", 64, 48, 24, 6, 20], 29664, {"FS_DEBUG_XCHG": "0", "FS_JACOBI_DEEP": "1"})
+
+
 def test_rccl_mgpcg_with_itself_as_neighbour():
     """MGPCG + vorticity confinement on the RCCL transport (window halos over send/recv, dot products
     over ncclAllReduce) against the host-staged transport, see slab_worker.self_peer_mgpcg."""
@@ -219,6 +252,7 @@ RCCL_CASES = [
     (2, (64, 48, 64), 3, 20, ["random"], {"FS_XCHG_STREAMS": "0"}),
     (4, (48, 40, 80), 3, 12, ["random"], {}),                        # interior ranks with two neighbours
     (8, (64, 64, 256), 2, 16, [], {}),                               # the strong-scaling layout of an 8-GPU node
+    (2, (64, 48, 64), 3, 20, ["random", "deep"], {"FS_JACOBI_DEEP": "1"}),   # six-sweep passes, then a pair
 ]
 
 

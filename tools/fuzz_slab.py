@@ -79,6 +79,8 @@ def main():
         vel = float(rng.choice([0.3, 1.5]))     # (faster fields leave the ghost planes: FS_ERR_HALO, tested elsewhere)
         os.environ["FS_JACOBI_CFG"] = str(int(rng.integers(0, 4)))
         os.environ["FS_JACOBI_TUNE"] = "0"
+        # six-sweep passes where the slabs can take them (17 planes, 8 ghost planes, 14 rows)
+        os.environ["FS_JACOBI_DEEP"] = str(int(rng.integers(0, 2)))
         state_seed = int(rng.integers(1, 1 << 30))
         kw = dict(jacobi_iters=k, scheme=scheme, source_y=min(10.0, ny / 3.0), source_radius=min(7.0, min(nx, ny, nz) / 4.0))
         gkw, okw = dict(kw, device=dev), dict(kw)
@@ -88,8 +90,9 @@ def main():
         if mgpcg:
             gkw.update(pressure_solver=fs.FS_PRESSURE_MGPCG, mg_level=mg_level)
             okw.update(pressure_solver=oracle.PRESSURE_MGPCG, mg_level=mg_level)
-        desc = "case %d: %dx%dx%d on %d ranks, scheme %d k %d confine %d mgpcg %d steps %d vel %.1f cfg %s" % (
-            case, nx, ny, nz, world, scheme, k, confine, mgpcg, steps, vel, os.environ["FS_JACOBI_CFG"])
+        desc = "case %d: %dx%dx%d on %d ranks, scheme %d k %d confine %d mgpcg %d steps %d vel %.1f cfg %s deep %s" % (
+            case, nx, ny, nz, world, scheme, k, confine, mgpcg, steps, vel, os.environ["FS_JACOBI_CFG"],
+            os.environ["FS_JACOBI_DEEP"])
         if mgpcg:
             desc += " levels %d tb_min %s ghost %s" % (mg_level, os.environ["FS_MG_TB_MIN"], os.environ["FS_MG_SLAB_GHOST"])
         bad = []
