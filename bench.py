@@ -109,14 +109,21 @@ VALU_CYCLES_PER_INST = 2.0     # one wave-level vector instruction per SIMD ever
 SIMDS = 1024                   # 256 CUs x 4
 
 
-def load_pmc(kernel, workload):
+def load_pmc(kernel, workload, ran=None):
     """(entry, stale) of a kernel class from the committed rocprofv3 --pmc passes: HBM bytes per
-    launch and wave-level VALU instructions per launch.  stale = measured on other kernel sources."""
+    launch and wave-level VALU instructions per launch.  stale = measured on other kernel sources.
+    `ran`: the kernel this run launched for the Jacobi passes (rocprofv3's name without the
+    namespace); an entry measured on another variant (the timing at creation picked differently,
+    or a switch forced one) is not this run's and is dropped."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
         e = d.get("kernels", {}).get(kernel, {}).get(workload)
+        if e and kernel == "jacobi" and ran is not None:
+            measured = (d.get("jacobi_kernel") or {}).get(workload, "")
+            if ran not in measured:
+                e = None
         return e, d.get("source_hash") != kernel_source_hash()
     except Exception:
         return None, True
@@ -155,7 +162,7 @@ def valu_roofline(pmc, ms_per_launch):
             "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "avg_launch_ms": ms_per_launch}
 
 
-def stage_rooflines(prof, cells, steps, iters, n):
+def stage_rooflines(prof, cells, steps, iters, n, jacobi_ran=None):
     """Per stage: algorithmic bytes per step / device time per step against the HBM peak, and for
     the gather kernels, whose limiter is instruction issue, the share of the chip's vector-issue
     rate (1024 SIMDs x one wave instruction per 2 cycles at the clock of the counter pass) their
@@ -169,7 +176,7 @@ def stage_rooflines(prof, cells, steps, iters, n):
         bpc = BYTES_PER_CELL[name] * (iters if name == "jacobi" else 1)
         gbs = bpc * cells * steps / (ms * 1e-3) / 1e9
         e = {"ms_per_step": ms / steps, "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
-        pmc, stale = load_pmc(name, "%d^3" % n)
+        pmc, stale = load_pmc(name, "%d^3" % n, jacobi_ran)
         if pmc and not stale:
             per_step = launches / steps if name == "jacobi" else 1.0
             e["hbm_traffic_gbs"] = pmc["hbm_bytes_per_launch"] * per_step / (ms / steps * 1e-3) / 1e9
@@ -450,11 +457,12 @@ def main():
             algo_bytes = BYTES_PER_CELL.get(dom, 0.0) * cells_rank * args.steps / max(dom_launches, 1)
         avg_launch_s = dom_ms / max(dom_launches, 1) * 1e-3
         achieved = algo_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        pmc, stale = load_pmc(dom, "%d^3" % n)
-        usable = pmc and not stale and world == 1 and args.flow == "plume" and not args.fmad
-        traffic = float(pmc["hbm_bytes_per_launch"]) if usable else None
         cfg = solver.jacobi_config()
         fused_div = world == 1
+        jacobi_ran = rocprof_kernel_name("jacobi", cfg, args.scheme, fused_div, world > 1)
+        pmc, stale = load_pmc(dom, "%d^3" % n, jacobi_ran)
+        usable = pmc and not stale and world == 1 and args.flow == "plume" and not args.fmad
+        traffic = float(pmc["hbm_bytes_per_launch"]) if usable else None
         stage_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
         out = {
             "metric": "cell-updates/sec per step (incl. pressure iters)",
@@ -478,7 +486,7 @@ def main():
             "stage_ms_per_step": stage_ms,
             # secondary metric: lattice updates per second of the pressure sweeps alone (per GPU)
             "jacobi_lups": (cells_rank * sweeps_done / (prof["jacobi"][0] * 1e-3)) if prof.get("jacobi", (0, 0))[0] > 0 else None,
-            "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, sweeps_done / args.steps, n),
+            "stage_roofline": stage_rooflines(prof, cells_rank, args.steps, sweeps_done / args.steps, n, jacobi_ran),
             "autotune": {"jacobi_tile_variant": cfg["variant"], "jacobi_tile_rows": cfg["tile_rows"],
                          "jacobi_aligned_rows": cfg["aligned_rows"], "jacobi_planes_per_chunk": cfg["planes_per_chunk"],
                          "jacobi_nontemporal_stores": cfg["nontemporal_stores"],
@@ -532,7 +540,7 @@ def main():
             out["exchanges_per_step"] = halo["exchanges"] / args.steps
         if traffic is None and world == 1:
             out["roofline"]["traffic_note"] = ("no counter pass of these kernel sources is committed"
-                                               if stale else "no counter entry for this workload")
+                                               if stale else "no counter entry for this workload and kernel variant")
         if args.tolerance > 0:
             out["config"]["tolerance"] = args.tolerance
             out["config"]["check_every"] = args.check_every

@@ -50,6 +50,14 @@ def test_counter_summary_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     assert bench.load_pmc("jacobi", "256^3") == (None, False)
     (prof / "pmc_traffic.json").write_text(json.dumps({"source_hash": "other", "kernels": {"jacobi": {"512^3": entry}}}))
     assert bench.load_pmc("jacobi", "512^3") == (entry, True)
+    # ... and to the variant of the Jacobi kernel the counters were collected on
+    ran = "k_jacobi_deep<6, 48, 1>"
+    (prof / "pmc_traffic.json").write_text(json.dumps({
+        "source_hash": h, "jacobi_kernel": {"512^3": "void (anonymous namespace)::%s((anonymous namespace)::TbArgs)" % ran},
+        "kernels": {"jacobi": {"512^3": entry}, "advect_velocity": {"512^3": entry}}}))
+    assert bench.load_pmc("jacobi", "512^3", ran) == (entry, False)
+    assert bench.load_pmc("jacobi", "512^3", "k_jacobi_tb<0, 4, 64, 1, 1, 1>") == (None, False)
+    assert bench.load_pmc("advect_velocity", "512^3", "k_jacobi_tb<0, 4, 64, 1, 1, 1>") == (entry, False)
 
 
 ENV = {}     # the environment open_slab_solver edits (a stand-in for os.environ)
