@@ -2,7 +2,7 @@
 """One-off parity check of a z-slab run at a BASELINE size against the CPU oracle.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node W --master-addr 127.0.0.1 \
-        --master-port P tools/check_slab_fullsize.py NX NY NZ STEPS SWEEPS [tolerance] [mgpcg] [confine]
+        --master-port P tools/check_slab_fullsize.py NX NY NZ STEPS SWEEPS [tolerance] [mgpcg] [confine] [random]
 
 W ranks share whatever GPUs the box has (host-staged halos over gloo, the transport of the test
 suite).  Rank 0 alone steps the single-domain oracle (minutes per step at 512 x 512 x 1024) and
@@ -10,7 +10,9 @@ broadcasts each of its fields; every rank compares its own planes bit for bit.  
 the step runs in convergence mode (sum r^2 all-reduced every 8 sweeps) and the oracle repeats the
 sweep count the slabs report.  `mgpcg` selects the MGPCG pressure solver (SWEEPS is then its
 iteration limit), `confine` adds vorticity confinement; together they are the configuration the
-reference ships.  Too slow for the test suite; its output is kept under profiles/.
+reference ships.  `random` starts from a seeded random state (velocities of about a cell per step,
+random density, temperature and pressure) instead of the zero state, so that every plane of every
+field holds data.  Too slow for the test suite; its output is kept under profiles/.
 """
 import os
 import sys
@@ -31,7 +33,7 @@ def main():
     from fluidsolver_amd.slab import SlabSolver
 
     nx, ny, nz, steps, k = (int(v) for v in sys.argv[1:6])
-    words = [w for w in sys.argv[6:] if w in ("mgpcg", "confine")]
+    words = [w for w in sys.argv[6:] if w in ("mgpcg", "confine", "random")]
     rest = [w for w in sys.argv[6:] if w not in words]
     tol = float(rest[0]) if rest else 0.0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -53,6 +55,17 @@ def main():
         import oracle
         o = oracle.Oracle(oracle.default_params(nx, ny, nz, **okw))
     ok = True
+    if "random" in words:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import random_fields
+        st = random_fields(nx, ny, nz, seed=77, vel_scale=1.5)     # the same on every rank
+        for fid, arr in st.items():
+            s.upload_global(fid, arr)
+            if rank == 0:
+                o.set(fid, arr)
+        del st
+    if rank == 0:
+        print("passes of %d sweeps" % s.jacobi_config()["sweeps_per_pass"], flush=True)
     for step in range(steps):
         t0 = time.perf_counter()
         s.step()
@@ -113,7 +126,7 @@ def main():
         print("%dx%dx%d on %d ranks, %d steps, %s%s: %s" % (nx, ny, nz, world, steps,
               ("convergence mode, tolerance %g" % tol) if tol > 0 else
               ("MGPCG, at most %d iterations" % k) if "mgpcg" in words else "%d sweeps" % k,
-              ", vorticity confinement" if "confine" in words else "",
+              (", vorticity confinement" if "confine" in words else "") + (", random initial state" if "random" in words else ""),
               "BIT-IDENTICAL to the oracle" if ok else "MISMATCH"), flush=True)
     sys.exit(0 if ok else 1)
 
