@@ -105,6 +105,57 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def measure_traffic(n, iters, cfg, ran, flags):
+    """HBM bytes one launch of the Jacobi kernel `ran` moves, measured now: two rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE cannot share one) over the headless C++ benchmark of the same library
+    on the same workload, as child processes, with the kernel variant pinned to the one this run
+    timed.  Returns (bytes per launch, description) or (None, reason).  FETCH_SIZE / WRITE_SIZE are
+    in KiB; on gfx950 FETCH_SIZE counts the 128-byte requests of wide coalesced streams as 64 bytes,
+    so the read side is doubled (tools/pmc_to_json.py applies the same correction)."""
+    import csv
+    import shutil
+    import tempfile
+    exe = os.path.join(ROOT, "fluidsolver_amd", "bin", "fs_bench")
+    prof = shutil.which("rocprofv3")
+    if not prof or not os.path.exists(exe):
+        return None, "rocprofv3 or fluidsolver_amd/bin/fs_bench not found"
+    env = dict(os.environ)
+    deep = (cfg.get("sweeps_per_pass") or 4) > 4
+    env.update(FS_JACOBI_TUNE="0", FS_JACOBI_CFG=str(max(cfg["variant"], 0)), FS_JACOBI_NT=str(cfg["nontemporal_stores"]),
+               FS_JACOBI_DEEP="1" if deep else "0", TMPDIR="/tmp")
+    if cfg["planes_per_chunk"] > 0:
+        env["FS_JACOBI_LZ"] = str(cfg["planes_per_chunk"])
+    if deep:
+        env.update(FS_JACOBI_DEEP_LZ=str(cfg.get("deep_planes_per_chunk") or 0),
+                   FS_JACOBI_DEEP_NT=str(cfg.get("deep_nontemporal_stores") or 0))
+    got = {}
+    work = tempfile.mkdtemp(prefix="fs_traffic_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            # (the program itself follows `--`: the profiler's library has initialised the GPU by
+            # then, and a launcher in between would replace a process that has)
+            cmd = ["timeout", "-s", "KILL", "120", prof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p",
+                   "--", exe, str(n), str(iters), "4", "2", "-", str(flags)]
+            r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if r.returncode != 0:
+                return None, "the %s pass ended with status %d" % (counter, r.returncode)
+            vals = []
+            for dirpath, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        with open(os.path.join(dirpath, f)) as fh:
+                            vals += [float(row["Counter_Value"]) for row in csv.DictReader(fh)
+                                     if row["Counter_Name"] == counter and ran in row["Kernel_Name"]]
+            if not vals:
+                return None, "no %s rows for %s" % (counter, ran)
+            got[counter] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    total = got["FETCH_SIZE"] * 1024.0 * 2.0 + got["WRITE_SIZE"] * 1024.0
+    return total, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of fs_bench run by this invocation (reads x2)"
+
+
 VALU_CYCLES_PER_INST = 2.0     # one wave-level vector instruction per SIMD every 2 cycles (nominal)
 SIMDS = 1024                   # 256 CUs x 4
 
@@ -317,6 +368,9 @@ def main():
     ap.add_argument("--check-every", type=int, default=8)
     ap.add_argument("--fmad", action="store_true",
                     help="FS_FLAG_FMAD: the contracted arithmetic of the advection and the buoyancy (not the default contract)")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="N = 1: measure roofline.traffic now with two rocprofv3 --pmc passes of fluidsolver_amd/bin/fs_bench "
+                         "(child processes, ~10 s) instead of reading the committed profiles/pmc_traffic.json")
     ap.add_argument("--flow", choices=("plume", "swirl"), default="plume",
                     help="plume = BASELINE's workload (zero state + sphere source); swirl = a developed flow uploaded "
                          "before the warm-up steps (times the advection off its all-lanes-in-brick fast path; N = 1)")
@@ -463,6 +517,13 @@ def main():
         pmc, stale = load_pmc(dom, "%d^3" % n, jacobi_ran)
         usable = pmc and not stale and world == 1 and args.flow == "plume" and not args.fmad
         traffic = float(pmc["hbm_bytes_per_launch"]) if usable else None
+        traffic_source = None if traffic is None else "profiles/pmc_traffic.json (%s)" % pmc.get("source", "?")
+        if args.measure_traffic and world == 1 and dom == "jacobi" and args.flow == "plume":
+            live, how = measure_traffic(n, args.iters, cfg, jacobi_ran, flags)
+            if live is not None:
+                traffic, traffic_source = live, how
+            else:
+                print("bench.py: --measure-traffic: %s; keeping %s" % (how, traffic_source), file=sys.stderr)
         stage_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
         out = {
             "metric": "cell-updates/sec per step (incl. pressure iters)",
@@ -517,7 +578,7 @@ def main():
                 # of the same kernel sources, from the committed counter pass)
                 "traffic": traffic,
                 "frac_real": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_launch_s > 0 else None,
-                "traffic_source": (None if traffic is None else "profiles/pmc_traffic.json (%s)" % pmc.get("source", "?")),
+                "traffic_source": traffic_source,
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": dom_launches,
                 "algorithmic_bytes_per_launch": algo_bytes,

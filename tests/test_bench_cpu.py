@@ -60,6 +60,19 @@ def test_counter_summary_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     assert bench.load_pmc("advect_velocity", "512^3", "k_jacobi_tb<0, 4, 64, 1, 1, 1>") == (entry, False)
 
 
+def test_live_traffic_measurement_reports_why_it_cannot_run(monkeypatch):
+    """--measure-traffic without a profiler on the PATH: no number, a reason, and the caller keeps
+    the committed summary."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    cfg = {"variant": 2, "nontemporal_stores": 1, "planes_per_chunk": 103, "sweeps_per_pass": 6,
+           "deep_planes_per_chunk": 171, "deep_nontemporal_stores": 1}
+    got, why = bench.measure_traffic(512, 80, cfg, "k_jacobi_deep<6, 48, 1>", 0)
+    assert got is None and "rocprofv3" in why
+
+
 ENV = {}     # the environment open_slab_solver edits (a stand-in for os.environ)
 
 
