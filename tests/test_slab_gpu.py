@@ -113,7 +113,7 @@ def test_slab_six_sweep_passes(world, dims, steps, k, env):
     six valid ghost planes, the boundary planes next to each neighbour first, one exchange per pass
     hidden behind the interior; the last six-sweep pass sends the 8 planes the pair of four-sweep
     passes after it wants."""
-    run_ranks(world, ["host", *dims, steps, k, "random", "deep"], 29770 + world + k, dict(env, FS_JACOBI_DEEP="1"))
+    run_ranks(world, ["host", *dims, steps, k, "random", "deep"], 29771 + 2 * world + k % 11, dict(env, FS_JACOBI_DEEP="1"))
 
 
 def test_slab_six_sweep_passes_need_thick_slabs_and_deep_ghosts():
