@@ -580,6 +580,10 @@ def main():
                 "frac_real": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_launch_s > 0 else None,
                 "traffic_source": traffic_source,
                 "avg_launch_ms": avg_launch_s * 1e3,
+                # what to compare between kernel variants: device time per sweep and cell, not `frac`
+                # (a pass that fuses more sweeps moves the same bytes in a longer launch, so its
+                # `frac` and `frac_real` fall while its sweeps per second rise)
+                "us_per_sweep": (avg_launch_s * 1e6 / sweeps_per_launch) if sweeps_per_launch > 0 else None,
                 "launches": dom_launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
